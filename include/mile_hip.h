@@ -1,0 +1,168 @@
+/*
+ * mile_hip.h -- C ABI of the MI355X-native MCLMC ensemble sampler (libmile_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of zhiyuan-yang/MILE: the MCLMC
+ * integrator step over an ensemble of BNN-parameter particles with the
+ * per-particle full-batch grad-log-posterior of the FCN MLP.  Every entry point
+ * names the reference interface it replaces (paths relative to the reference
+ * repository root).  The reference binds that path through Python callables
+ * (blackjax.mclmc(logdensity_fn, L, step_size) -> SamplingAlgorithm(init, step));
+ * a Python closure cannot cross a C ABI, so the closure's CONTENT crosses
+ * instead: the model spec (src/config/models/fcn.py:7-30), the prior
+ * (src/training/priors.py:67-91), the task (src/training/probabilistic.py:92-109)
+ * and the training data (src/training/trainer.py:576-580).
+ *
+ * Conventions
+ *   - All array pointers are DEVICE pointers into caller-owned memory (PyTorch-ROCm
+ *     tensors), contiguous, row-major, fp32 unless stated.  The library never
+ *     frees or retains caller memory beyond the call, except mile_set_data which
+ *     COPIES X and y into its own padded layout.
+ *   - [E, d] arrays: one row per particle (chain), d = mile_param_count(), in
+ *     jax.flatten_util.ravel_pytree order of the FCN param tree: for each layer in
+ *     sorted-name order ('layer0','layer1','layer10','layer11','layer2',...):
+ *     bias[out] then kernel[in, out] row-major (src/training/priors.py:105,
+ *     src/training/warmup.py:341,442).
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued on it and the
+ *     call returns without synchronising.  No internal threads.
+ *   - Return value: 0 on success, negative mile_status on error; the message is
+ *     available from mile_last_error() (thread-local).
+ *   - One handle per device; a handle is not thread-safe; distinct handles are
+ *     independent.
+ */
+#ifndef MILE_HIP_H_
+#define MILE_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MILE_ABI_VERSION 1
+#define MILE_MAX_LAYERS 16
+
+typedef enum mile_status {
+  MILE_OK = 0,
+  MILE_ERR_INVALID = -1,     /* bad argument / unsupported spec */
+  MILE_ERR_STATE = -2,       /* call order (e.g. no data set, workspace too small) */
+  MILE_ERR_HIP = -3,         /* HIP runtime error */
+  MILE_ERR_NOMEM = -4
+} mile_status;
+
+/* src/config/models/base.py:25-39 (Activation) */
+typedef enum mile_activation { MILE_ACT_RELU = 0, MILE_ACT_TANH = 1, MILE_ACT_SIGMOID = 2 } mile_activation;
+/* src/config/data.py Task; likelihoods at src/training/probabilistic.py:92-109 */
+typedef enum mile_task { MILE_TASK_REGRESSION = 0, MILE_TASK_CLASSIFICATION = 1 } mile_task;
+/* src/training/priors.py:47-49 (StandardNormal == NORMAL with loc 0, scale 1) */
+typedef enum mile_prior { MILE_PRIOR_NORMAL = 0, MILE_PRIOR_LAPLACE = 1 } mile_prior;
+/* Placement of the partial momentum refresh inside one kernel step. */
+typedef enum mile_refresh { MILE_REFRESH_O_STEP_O = 0, MILE_REFRESH_STEP_O = 1 } mile_refresh;
+/* Which grad-log-posterior kernel to use.  AUTO picks the fastest that supports the spec. */
+typedef enum mile_grad_kernel { MILE_GRAD_AUTO = 0, MILE_GRAD_GENERIC = 1, MILE_GRAD_MFMA_W64 = 2 } mile_grad_kernel;
+
+/* FCNConfig (src/config/models/fcn.py:7-30) + PriorConfig (src/config/sampler.py:60-95)
+ * + Task: everything log_unnormalized_posterior (src/training/probabilistic.py:115-138)
+ * closes over, apart from the data. */
+typedef struct mile_model_spec {
+  int32_t in_features;               /* F: columns of X */
+  int32_t n_layers;                  /* len(hidden_structure); last entry is the output layer */
+  int32_t widths[MILE_MAX_LAYERS];   /* hidden_structure */
+  int32_t activation;                /* mile_activation, between layers, none after the last */
+  int32_t task;                      /* mile_task: regr -> output width 2 (mu, log sigma) */
+  int32_t prior;                     /* mile_prior */
+  float prior_loc;
+  float prior_scale;
+  int32_t use_bias;                  /* FCNConfig.use_bias; only 1 is supported */
+} mile_model_spec;
+
+/* blackjax IntegratorState(position, momentum, logdensity, logdensity_grad) for an
+ * ensemble (src/types.py:17-27 State is its `position` prefix). */
+typedef struct mile_state {
+  int32_t n_particles;       /* E */
+  float *position;           /* [E, d] */
+  float *momentum;           /* [E, d], unit rows */
+  float *logdensity;         /* [E] */
+  float *logdensity_grad;    /* [E, d] */
+} mile_state;
+
+/* Arguments of n_steps kernel steps == the lax.scan body of
+ * src/training/sampling.py:140-178 run n_steps times. */
+typedef struct mile_step_args {
+  const float *step_size;        /* [E] per-chain step size (warmup_params.txt line 1) */
+  const float *L;                /* [E] per-chain momentum decoherence length (line 2) */
+  const float *sqrt_diag_cov;    /* [E, d] or NULL (== 1.0, what blackjax.mclmc defaults to) */
+  const float *noise;            /* [n_steps, 2, E, d] N(0,1) draws (parity mode) or NULL */
+  uint64_t seed;                 /* counter RNG (Philox4x32-10 + Box-Muller) when noise == NULL */
+  const int32_t *particle_ids;   /* [E] GLOBAL chain ids keying the RNG streams, or NULL => 0..E-1 */
+  int64_t step_offset;           /* index of the first step: RNG counter and thinning predicate */
+  int32_t n_steps;
+  int32_t n_thinning;            /* keep position when (step_offset+i) % n_thinning == 0; <=0: keep none */
+  int32_t refresh;               /* mile_refresh */
+  float *out_samples;            /* [n_kept, E, d] kept positions in step order, or NULL */
+  float *out_info;               /* [n_steps, E, 3] (logdensity, kinetic_change, energy_change) or NULL */
+} mile_step_args;
+
+typedef struct mile_sampler mile_sampler;
+
+const char *mile_last_error(void);
+int32_t mile_abi_version(void);
+
+/* Replaces: config.kernel(logdensity_fn, ...) construction of the target, i.e.
+ * ProbabilisticModel.__init__ (src/training/probabilistic.py:19-47) + Prior.from_name
+ * (src/training/priors.py:67-91).  `device` is the HIP device ordinal. */
+int32_t mile_create(const mile_model_spec *spec, int32_t device, mile_sampler **out);
+int32_t mile_destroy(mile_sampler *s);
+
+/* pytree_size(position) (blackjax.util; src/training/warmup.py:203). */
+int64_t mile_param_count(const mile_sampler *s);
+
+/* Offsets of layer `layer`'s bias and kernel inside the raveled vector (ravel_pytree order). */
+int32_t mile_param_offsets(const mile_sampler *s, int32_t layer, int64_t *bias_off, int64_t *kernel_off);
+
+/* Replaces: partial(log_unnormalized_posterior, x=train_x, y=train_y)
+ * (src/training/trainer.py:576-580).  X [N, F] fp32; y [N] fp32 (regr) or int32 (classification). */
+int32_t mile_set_data(mile_sampler *s, const float *X, const void *y, int64_t N, void *stream);
+
+/* Size the internal workspace (partial-gradient slabs etc.) for ensembles of up to E
+ * particles.  Allocation happens here, never inside a launch call. */
+int32_t mile_reserve(mile_sampler *s, int32_t E);
+
+/* Select the grad kernel (default AUTO). */
+int32_t mile_set_grad_kernel(mile_sampler *s, int32_t which);
+int32_t mile_get_grad_kernel(const mile_sampler *s);
+
+/* Replaces: jax.value_and_grad(logdensity_fn)(position) as used inside blackjax
+ * (integrators.py position update; mclmc.init).  theta [E, d] -> logp [E], grad [E, d]. */
+int32_t mile_logpost_grad(mile_sampler *s, const float *theta, int32_t E, float *logp, float *grad,
+                          void *stream);
+
+/* Replaces: blackjax.mcmc.mclmc.init(position, logdensity_fn, rng_key)
+ * (src/training/warmup.py:539-541).  Fills state->momentum = z/|z| with z = `noise` [E, d] if
+ * non-NULL, else Philox(seed, particle id, step 0, stage 2); evaluates logdensity and its
+ * gradient at state->position (which the caller has filled). */
+int32_t mile_init(mile_sampler *s, mile_state *state, const float *noise, uint64_t seed,
+                  const int32_t *particle_ids, void *stream);
+
+/* Replaces: the scan of sampler.step(rng_key, state) at src/training/sampling.py:140-178
+ * (blackjax.mclmc(...).step == build_kernel(...)(rng_key, state, L, step_size),
+ * src/training/warmup.py:286-291,427-432).  Advances `state` in place by n_steps. */
+int32_t mile_step(mile_sampler *s, mile_state *state, const mile_step_args *args, void *stream);
+
+/* Counter-RNG words/normals exactly as the step kernels draw them (test hook). out [E, d]. */
+int32_t mile_debug_noise(mile_sampler *s, uint64_t seed, const int32_t *particle_ids, int32_t E,
+                         int64_t step, int32_t stage, float *out, void *stream);
+
+/* Introspection for bench.py's roofline: name, workgroups and LDS bytes of the grad kernel
+ * that the current configuration launches for E particles. */
+int32_t mile_grad_launch_info(const mile_sampler *s, int32_t E, int32_t *grid_x, int32_t *grid_y,
+                              int32_t *block, int32_t *lds_bytes, char *name, int32_t name_len);
+
+/* HIP-event timing of the grad kernel launches only (on `stream`): call begin, run steps,
+ * call end -> total milliseconds and number of grad launches in between. */
+int32_t mile_grad_timing_begin(mile_sampler *s);
+int32_t mile_grad_timing_end(mile_sampler *s, float *total_ms, int32_t *n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MILE_HIP_H_ */

@@ -1,0 +1,49 @@
+"""Build libmile_hip.so in-tree with hipcc for gfx950 (MI355X).
+
+The .so is git-ignored but travels to the GPU box with the gpurun snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+CSRC = PKG_DIR / 'csrc'
+LIB_PATH = PKG_DIR / 'libmile_hip.so'
+SOURCES = ['mile_hip.hip']
+HEADERS = ['mile_device.h', 'mile_grad_generic.h', 'mile_grad_w64.h', 'mile_update.h']
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError('hipcc not found: libmile_hip.so cannot be built')
+
+
+def needs_build() -> bool:
+    if not LIB_PATH.exists():
+        return True
+    t = LIB_PATH.stat().st_mtime
+    deps = [CSRC / f for f in SOURCES + HEADERS] + [PKG_DIR.parent / 'include' / 'mile_hip.h']
+    return any(p.stat().st_mtime > t for p in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> Path:
+    """hipcc --offload-arch=gfx950 -shared -fPIC -> mile_amd/libmile_hip.so."""
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [_hipcc(), '-O3', '--offload-arch=gfx950', '-std=c++17', '-shared', '-fPIC',
+           '-o', str(LIB_PATH)] + [str(CSRC / f) for f in SOURCES]
+    if verbose:
+        print(' '.join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f'hipcc failed:\n{res.stdout}\n{res.stderr}')
+    return LIB_PATH
+
+
+if __name__ == '__main__':
+    print(build_library(force=True, verbose=True))

@@ -1,0 +1,465 @@
+// libmile_hip.so -- host side of the C ABI declared in include/mile_hip.h.
+// gfx950 (MI355X) only.  No torch types: plain pointers, sizes and a hipStream_t.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mile_device.h"
+#include "mile_grad_generic.h"
+#include "mile_grad_w64.h"
+#include "mile_update.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      return fail(MILE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));           \
+  } while (0)
+
+static const double MCLACHLAN_B1 = 0.1931833275037836;
+
+struct mile_sampler {
+  mile_model_spec spec{};
+  DevSpec ds{};
+  int device = 0;
+  int n_cu = 256;
+  // data
+  float *X = nullptr, *Xp = nullptr;
+  void *y = nullptr;
+  int N = 0, Npad = 0, Fp = 0;
+  // workspace
+  int E_cap = 0, S_cap = 0;
+  float *slabs = nullptr, *llpart = nullptr, *dK = nullptr, *lold = nullptr;
+  int grad_kernel = MILE_GRAD_AUTO;
+  // timing of grad launches
+  bool timing = false;
+  std::vector<hipEvent_t> ev;
+  size_t ev_used = 0;
+};
+
+static bool w64_supported(const mile_model_spec &sp) {
+  if (sp.task != MILE_TASK_REGRESSION || sp.activation != MILE_ACT_RELU) return false;
+  const int nh = sp.n_layers - 1;
+  if (nh < 1 || nh > 3) return false;
+  for (int l = 0; l < nh; ++l)
+    if (sp.widths[l] != 64) return false;
+  if (sp.widths[nh] != 2) return false;
+  if (sp.in_features > 16) return false;
+  return true;
+}
+
+static int resolved_kernel(const mile_sampler *s) {
+  if (s->grad_kernel == MILE_GRAD_AUTO) return w64_supported(s->spec) ? MILE_GRAD_MFMA_W64 : MILE_GRAD_GENERIC;
+  return s->grad_kernel;
+}
+
+// rows per LDS tile of the generic kernel: fit the activation record in ~56 KiB
+static int generic_R(const DevSpec &ds) {
+  const int per_row = ds.act_stride + 2 * ds.max_width;
+  int R = (56 * 1024 / 4 - 16) / per_row;
+  R = std::max(1, std::min(R, 64));
+  return R;
+}
+
+static int choose_S(const mile_sampler *s, int E, int kernel) {
+  if (kernel == MILE_GRAD_MFMA_W64) {
+    const int NB = s->Npad / 32;
+    int S = std::max(1, s->n_cu / std::max(E, 1));
+    S = std::min(S, std::max(1, NB / 4));  // keep >= 4 row blocks (one per wave) per workgroup
+    return S;
+  }
+  int S = std::max(1, (2 * s->n_cu) / std::max(E, 1));
+  S = std::min(S, std::max(1, s->N / 64));
+  return std::min(S, 64);
+}
+
+extern "C" {
+
+const char *mile_last_error(void) { return g_err.c_str(); }
+int32_t mile_abi_version(void) { return MILE_ABI_VERSION; }
+
+int32_t mile_create(const mile_model_spec *spec, int32_t device, mile_sampler **out) {
+  if (!spec || !out) return fail(MILE_ERR_INVALID, "mile_create: null argument");
+  if (spec->n_layers < 1 || spec->n_layers > MILE_MAX_LAYERS) return fail(MILE_ERR_INVALID, "n_layers out of range");
+  if (spec->in_features < 1) return fail(MILE_ERR_INVALID, "in_features must be >= 1");
+  if (!spec->use_bias) return fail(MILE_ERR_INVALID, "use_bias=false is not supported");
+  if (spec->activation < 0 || spec->activation > MILE_ACT_SIGMOID) return fail(MILE_ERR_INVALID, "unknown activation");
+  if (spec->task != MILE_TASK_REGRESSION && spec->task != MILE_TASK_CLASSIFICATION) return fail(MILE_ERR_INVALID, "unknown task");
+  if (spec->prior != MILE_PRIOR_NORMAL && spec->prior != MILE_PRIOR_LAPLACE) return fail(MILE_ERR_INVALID, "unknown prior");
+  if (!(spec->prior_scale > 0.0f)) return fail(MILE_ERR_INVALID, "prior_scale must be > 0");
+  for (int l = 0; l < spec->n_layers; ++l)
+    if (spec->widths[l] < 1) return fail(MILE_ERR_INVALID, "layer width must be >= 1");
+  if (spec->task == MILE_TASK_REGRESSION && spec->widths[spec->n_layers - 1] != 2)
+    return fail(MILE_ERR_INVALID, "regression needs an output layer of width 2 (mu, log sigma)");
+
+  auto *s = new mile_sampler();
+  s->spec = *spec;
+  s->device = device;
+  DevSpec &ds = s->ds;
+  ds.n_layers = spec->n_layers;
+  ds.in_features = spec->in_features;
+  ds.activation = spec->activation;
+  ds.task = spec->task;
+  ds.prior = spec->prior;
+  ds.prior_loc = spec->prior_loc;
+  ds.prior_scale = spec->prior_scale;
+  // ravel_pytree order: layers sorted by NAME ("layer10" < "layer2"), bias before kernel
+  std::vector<int> order(spec->n_layers);
+  for (int i = 0; i < spec->n_layers; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [](int a, int b) {
+    return std::string("layer") + std::to_string(a) < std::string("layer") + std::to_string(b);
+  });
+  long long off = 0;
+  for (int li : order) {
+    const int fin = li == 0 ? spec->in_features : spec->widths[li - 1], fout = spec->widths[li];
+    ds.b_off[li] = (int)off; off += fout;
+    ds.w_off[li] = (int)off; off += (long long)fin * fout;
+  }
+  if (off > 0x7fffffffLL) { delete s; return fail(MILE_ERR_INVALID, "parameter count exceeds int32"); }
+  if (off < 2) { delete s; return fail(MILE_ERR_INVALID, "The target distribution must have more than 1 dimension for MCLMC."); }
+  ds.d = (int)off;
+  ds.act_off[0] = 0;
+  int a = spec->in_features, mw = spec->in_features;
+  for (int l = 0; l < spec->n_layers; ++l) {
+    ds.widths[l] = spec->widths[l];
+    ds.act_off[l + 1] = a;
+    a += spec->widths[l];
+    mw = std::max(mw, spec->widths[l]);
+  }
+  ds.act_stride = a;
+  ds.max_width = mw;
+  if (generic_R(ds) < 1) { delete s; return fail(MILE_ERR_INVALID, "network too wide for the generic kernel"); }
+
+  int cnt = 0;
+  hipError_t e = hipGetDeviceCount(&cnt);
+  if (e == hipSuccess && device < cnt) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
+  }
+  *out = s;
+  return MILE_OK;
+}
+
+static void free_data(mile_sampler *s) {
+  if (s->X) (void)hipFree(s->X);
+  if (s->Xp) (void)hipFree(s->Xp);
+  if (s->y) (void)hipFree(s->y);
+  s->X = s->Xp = nullptr; s->y = nullptr;
+}
+static void free_ws(mile_sampler *s) {
+  if (s->slabs) (void)hipFree(s->slabs);
+  if (s->llpart) (void)hipFree(s->llpart);
+  if (s->dK) (void)hipFree(s->dK);
+  if (s->lold) (void)hipFree(s->lold);
+  s->slabs = s->llpart = s->dK = s->lold = nullptr;
+  s->E_cap = s->S_cap = 0;
+}
+
+int32_t mile_destroy(mile_sampler *s) {
+  if (!s) return MILE_OK;
+  free_data(s);
+  free_ws(s);
+  for (auto ev : s->ev) (void)hipEventDestroy(ev);
+  delete s;
+  return MILE_OK;
+}
+
+int64_t mile_param_count(const mile_sampler *s) { return s ? s->ds.d : -1; }
+
+int32_t mile_param_offsets(const mile_sampler *s, int32_t layer, int64_t *bias_off, int64_t *kernel_off) {
+  if (!s || layer < 0 || layer >= s->ds.n_layers) return fail(MILE_ERR_INVALID, "mile_param_offsets: bad layer");
+  if (bias_off) *bias_off = s->ds.b_off[layer];
+  if (kernel_off) *kernel_off = s->ds.w_off[layer];
+  return MILE_OK;
+}
+
+__global__ void k_pad_x(const float *X, float *Xp, int N, int Npad, int F, int Fp) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)Npad * Fp) return;
+  const int r = (int)(idx / Fp), c = (int)(idx % Fp);
+  Xp[idx] = (r < N && c < F) ? X[(long long)r * F + c] : 0.0f;
+}
+
+int32_t mile_set_data(mile_sampler *s, const float *X, const void *y, int64_t N, void *stream) {
+  if (!s || !X || !y) return fail(MILE_ERR_INVALID, "mile_set_data: null argument");
+  if (N < 1 || N > 0x3fffffff) return fail(MILE_ERR_INVALID, "mile_set_data: N out of range");
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipSetDevice(s->device));
+  free_data(s);
+  free_ws(s);
+  const int F = s->spec.in_features;
+  s->N = (int)N;
+  s->Npad = ((int)N + 31) / 32 * 32;
+  s->Fp = (F + 7) / 8 * 8;
+  HIP_TRY(hipMalloc(&s->X, (size_t)N * F * 4));
+  HIP_TRY(hipMalloc(&s->Xp, (size_t)s->Npad * s->Fp * 4));
+  HIP_TRY(hipMalloc(&s->y, (size_t)s->Npad * 4));
+  HIP_TRY(hipMemcpyAsync(s->X, X, (size_t)N * F * 4, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemsetAsync(s->y, 0, (size_t)s->Npad * 4, st));
+  HIP_TRY(hipMemcpyAsync(s->y, y, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
+  const long long tot = (long long)s->Npad * s->Fp;
+  k_pad_x<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(s->X, s->Xp, s->N, s->Npad, F, s->Fp);
+  HIP_TRY(hipGetLastError());
+  return MILE_OK;
+}
+
+int32_t mile_reserve(mile_sampler *s, int32_t E) {
+  if (!s || E < 1) return fail(MILE_ERR_INVALID, "mile_reserve: bad argument");
+  if (!s->X) return fail(MILE_ERR_STATE, "mile_reserve: call mile_set_data first");
+  HIP_TRY(hipSetDevice(s->device));
+  // capacity must cover whichever grad kernel is selected later
+  const int S = std::max(choose_S(s, E, MILE_GRAD_GENERIC),
+                         w64_supported(s->spec) ? choose_S(s, E, MILE_GRAD_MFMA_W64) : 1);
+  if (E <= s->E_cap && S <= s->S_cap) return MILE_OK;
+  free_ws(s);
+  HIP_TRY(hipMalloc(&s->slabs, (size_t)E * S * s->ds.d * 4));
+  HIP_TRY(hipMalloc(&s->llpart, (size_t)E * S * 4));
+  HIP_TRY(hipMalloc(&s->dK, (size_t)E * 4));
+  HIP_TRY(hipMalloc(&s->lold, (size_t)E * 4));
+  s->E_cap = E;
+  s->S_cap = S;
+  return MILE_OK;
+}
+
+int32_t mile_set_grad_kernel(mile_sampler *s, int32_t which) {
+  if (!s) return fail(MILE_ERR_INVALID, "null handle");
+  if (which < MILE_GRAD_AUTO || which > MILE_GRAD_MFMA_W64) return fail(MILE_ERR_INVALID, "unknown grad kernel");
+  if (which == MILE_GRAD_MFMA_W64 && !w64_supported(s->spec))
+    return fail(MILE_ERR_INVALID, "MFMA_W64 needs ReLU regression with 1-3 hidden layers of width 64 and F <= 16");
+  s->grad_kernel = which;
+  return MILE_OK;
+}
+int32_t mile_get_grad_kernel(const mile_sampler *s) { return s ? resolved_kernel(s) : MILE_ERR_INVALID; }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------
+// grad launch
+// ------------------------------------------------------------------------------------
+template <int NH, int FQ>
+static hipError_t launch_w64(const GradParams &gp, int E, hipStream_t st) {
+  using LY = W64Layout<NH, FQ>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)k_grad_w64<NH, FQ>, hipFuncAttributeMaxDynamicSharedMemorySize, LY::BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  k_grad_w64<NH, FQ><<<dim3(gp.S, E), 256, LY::BYTES, st>>>(gp);
+  return hipGetLastError();
+}
+
+template <int NH, int FQ>
+static int w64_lds_bytes() { return W64Layout<NH, FQ>::BYTES; }
+
+static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t st) {
+  if (!s->X) return fail(MILE_ERR_STATE, "no data: call mile_set_data first");
+  const int kernel = resolved_kernel(s);
+  const int S = choose_S(s, E, kernel);
+  if (E > s->E_cap || S > s->S_cap) return fail(MILE_ERR_STATE, "workspace too small: call mile_reserve(E) first");
+  GradParams gp;
+  gp.spec = s->ds;
+  gp.theta = theta;
+  gp.X = s->X; gp.Xp = s->Xp; gp.y = s->y;
+  gp.slabs = s->slabs; gp.llpart = s->llpart;
+  gp.N = s->N; gp.Npad = s->Npad; gp.Fp = s->Fp; gp.S = S; gp.R = generic_R(s->ds);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (s->timing) {
+    if (s->ev_used + 2 > s->ev.size()) {
+      for (int k = 0; k < 2; ++k) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreate(&ev));
+        s->ev.push_back(ev);
+      }
+    }
+    e0 = s->ev[s->ev_used]; e1 = s->ev[s->ev_used + 1];
+    s->ev_used += 2;
+    HIP_TRY(hipEventRecord(e0, st));
+  }
+  if (kernel == MILE_GRAD_MFMA_W64) {
+    const int nh = s->spec.n_layers - 1, fq = s->Fp / 8;
+    hipError_t e = hipErrorInvalidValue;
+    if (nh == 1 && fq == 1) e = launch_w64<1, 1>(gp, E, st);
+    else if (nh == 2 && fq == 1) e = launch_w64<2, 1>(gp, E, st);
+    else if (nh == 3 && fq == 1) e = launch_w64<3, 1>(gp, E, st);
+    else if (nh == 1 && fq == 2) e = launch_w64<1, 2>(gp, E, st);
+    else if (nh == 2 && fq == 2) e = launch_w64<2, 2>(gp, E, st);
+    else if (nh == 3 && fq == 2) e = launch_w64<3, 2>(gp, E, st);
+    HIP_TRY(e);
+  } else {
+    const size_t lds = ((size_t)gp.R * (s->ds.act_stride + 2 * s->ds.max_width) + 16) * 4;
+    k_grad_generic<<<dim3(S, E), 256, lds, st>>>(gp);
+    HIP_TRY(hipGetLastError());
+  }
+  if (s->timing) HIP_TRY(hipEventRecord(e1, st));
+  return MILE_OK;
+}
+
+extern "C" {
+
+int32_t mile_grad_launch_info(const mile_sampler *s, int32_t E, int32_t *grid_x, int32_t *grid_y,
+                              int32_t *block, int32_t *lds_bytes, char *name, int32_t name_len) {
+  if (!s || !s->X) return fail(MILE_ERR_STATE, "mile_grad_launch_info: no data set");
+  const int kernel = resolved_kernel(s);
+  const int S = choose_S(s, E, kernel);
+  if (grid_x) *grid_x = S;
+  if (grid_y) *grid_y = E;
+  if (block) *block = 256;
+  int lds = 0;
+  const char *nm = "k_grad_generic";
+  if (kernel == MILE_GRAD_MFMA_W64) {
+    const int nh = s->spec.n_layers - 1, fq = s->Fp / 8;
+    nm = "k_grad_w64";
+    lds = nh == 1 ? (fq == 1 ? w64_lds_bytes<1, 1>() : w64_lds_bytes<1, 2>())
+        : nh == 2 ? (fq == 1 ? w64_lds_bytes<2, 1>() : w64_lds_bytes<2, 2>())
+                  : (fq == 1 ? w64_lds_bytes<3, 1>() : w64_lds_bytes<3, 2>());
+  } else {
+    lds = (int)(((size_t)generic_R(s->ds) * (s->ds.act_stride + 2 * s->ds.max_width) + 16) * 4);
+  }
+  if (lds_bytes) *lds_bytes = lds;
+  if (name && name_len > 0) { std::strncpy(name, nm, name_len - 1); name[name_len - 1] = 0; }
+  return MILE_OK;
+}
+
+int32_t mile_grad_timing_begin(mile_sampler *s) {
+  if (!s) return fail(MILE_ERR_INVALID, "null handle");
+  s->timing = true;
+  s->ev_used = 0;
+  return MILE_OK;
+}
+
+int32_t mile_grad_timing_end(mile_sampler *s, float *total_ms, int32_t *n_launches) {
+  if (!s) return fail(MILE_ERR_INVALID, "null handle");
+  s->timing = false;
+  double tot = 0.0;
+  const size_t n = s->ev_used / 2;
+  if (n) HIP_TRY(hipEventSynchronize(s->ev[s->ev_used - 1]));
+  for (size_t k = 0; k < n; ++k) {
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev[2 * k], s->ev[2 * k + 1]));
+    tot += ms;
+  }
+  if (total_ms) *total_ms = (float)tot;
+  if (n_launches) *n_launches = (int32_t)n;
+  s->ev_used = 0;
+  return MILE_OK;
+}
+
+int32_t mile_logpost_grad(mile_sampler *s, const float *theta, int32_t E, float *logp, float *grad, void *stream) {
+  if (!s || !theta || !logp || !grad || E < 1) return fail(MILE_ERR_INVALID, "mile_logpost_grad: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipSetDevice(s->device));
+  int rc = launch_grad(s, theta, E, st);
+  if (rc) return rc;
+  const int S = choose_S(s, E, resolved_kernel(s));
+  k_finalize<<<E, UPD_NT, 0, st>>>(s->ds.d, S, s->ds.prior, s->ds.prior_loc, s->ds.prior_scale, theta,
+                                   s->slabs, s->llpart, grad, logp);
+  HIP_TRY(hipGetLastError());
+  return MILE_OK;
+}
+
+int32_t mile_init(mile_sampler *s, mile_state *state, const float *noise, uint64_t seed,
+                  const int32_t *particle_ids, void *stream) {
+  if (!s || !state || !state->position || !state->momentum || !state->logdensity || !state->logdensity_grad)
+    return fail(MILE_ERR_INVALID, "mile_init: null state field");
+  const int E = state->n_particles;
+  if (E < 1) return fail(MILE_ERR_INVALID, "mile_init: n_particles must be >= 1");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = mile_logpost_grad(s, state->position, E, state->logdensity, state->logdensity_grad, stream);
+  if (rc) return rc;
+  k_init_momentum<<<E, UPD_NT, 0, st>>>(s->ds.d, noise, seed, particle_ids, state->momentum);
+  HIP_TRY(hipGetLastError());
+  return MILE_OK;
+}
+
+int32_t mile_step(mile_sampler *s, mile_state *state, const mile_step_args *a, void *stream) {
+  if (!s || !state || !a) return fail(MILE_ERR_INVALID, "mile_step: null argument");
+  if (!state->position || !state->momentum || !state->logdensity || !state->logdensity_grad)
+    return fail(MILE_ERR_INVALID, "mile_step: null state field");
+  if (!a->step_size || !a->L) return fail(MILE_ERR_INVALID, "mile_step: step_size and L are required");
+  if (a->n_steps < 0) return fail(MILE_ERR_INVALID, "mile_step: n_steps < 0");
+  if (a->refresh != MILE_REFRESH_O_STEP_O && a->refresh != MILE_REFRESH_STEP_O)
+    return fail(MILE_ERR_INVALID, "mile_step: unknown refresh mode");
+  const int E = state->n_particles, d = s->ds.d;
+  if (E < 1) return fail(MILE_ERR_INVALID, "mile_step: n_particles must be >= 1");
+  if (a->n_steps == 0) return MILE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipSetDevice(s->device));
+  const int kernel = resolved_kernel(s);
+  const int S = choose_S(s, E, kernel);
+  if (!s->X) return fail(MILE_ERR_STATE, "no data: call mile_set_data first");
+  if (E > s->E_cap || S > s->S_cap) return fail(MILE_ERR_STATE, "workspace too small: call mile_reserve(E) first");
+
+  UpdParams up{};
+  up.d = d; up.E = E; up.S = S;
+  up.prior = s->ds.prior; up.prior_loc = s->ds.prior_loc; up.prior_scale = s->ds.prior_scale;
+  up.x = state->position; up.u = state->momentum; up.g = state->logdensity_grad; up.logp = state->logdensity;
+  up.slabs = s->slabs; up.llpart = s->llpart;
+  up.eps = a->step_size; up.L = a->L; up.sdc = a->sqrt_diag_cov;
+  up.seed = a->seed; up.pids = a->particle_ids;
+  up.dK = s->dK; up.lold = s->lold;
+  const float b1 = (float)MCLACHLAN_B1, b2 = (float)(1.0 - 2.0 * MCLACHLAN_B1);
+  const bool oso = a->refresh == MILE_REFRESH_O_STEP_O;
+  const size_t Ed = (size_t)E * d;
+  auto noise_at = [&](int i, int k) -> const float * { return a->noise ? a->noise + ((size_t)i * 2 + k) * Ed : nullptr; };
+
+  int kept = 0;
+  for (int i = 0; i < a->n_steps; ++i) {
+    const int64_t gstep = a->step_offset + i;
+    if (i == 0) {  // O(z1) . B(b1) . A(1/2) from the cached gradient
+      UpdParams u = up;
+      u.flags = UPD_START | UPD_B2 | UPD_A | (oso ? UPD_OB : 0);
+      u.zB = noise_at(i, 0); u.stepB = (uint32_t)gstep; u.stageB = 0; u.hB = 0.5f;
+      u.coef_b2 = b1; u.coef_a = 0.5f;
+      k_update<<<E, UPD_NT, 0, st>>>(u);
+    }
+    int rc = launch_grad(s, state->position, E, st);
+    if (rc) return rc;
+    {  // B(1 - 2 b1) . A(1/2)
+      UpdParams u = up;
+      u.flags = UPD_FROM_SLABS | UPD_B1 | UPD_A;
+      u.coef_b1 = b2; u.coef_a = 0.5f;
+      k_update<<<E, UPD_NT, 0, st>>>(u);
+    }
+    rc = launch_grad(s, state->position, E, st);
+    if (rc) return rc;
+    {  // B(b1) . O(z2) . record  [ . O(z1') . B(b1) . A(1/2) of the next step ]
+      UpdParams u = up;
+      const bool last = (i == a->n_steps - 1);
+      u.flags = UPD_FROM_SLABS | UPD_B1 | UPD_OA | UPD_RECORD;
+      u.coef_b1 = b1;
+      u.zA = noise_at(i, 1); u.stepA = (uint32_t)gstep; u.stageA = 1; u.hA = oso ? 0.5f : 1.0f;
+      if (!last) {
+        u.flags |= UPD_B2 | UPD_A | (oso ? UPD_OB : 0);
+        u.zB = noise_at(i + 1, 0); u.stepB = (uint32_t)(gstep + 1); u.stageB = 0; u.hB = 0.5f;
+        u.coef_b2 = b1; u.coef_a = 0.5f;
+      }
+      if (a->out_info) u.out_info = a->out_info + (size_t)i * E * 3;
+      if (a->out_samples && a->n_thinning > 0 && (gstep % a->n_thinning) == 0) {
+        u.out_sample = a->out_samples + (size_t)kept * Ed;
+        ++kept;
+      }
+      k_update<<<E, UPD_NT, 0, st>>>(u);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return MILE_OK;
+}
+
+int32_t mile_debug_noise(mile_sampler *s, uint64_t seed, const int32_t *particle_ids, int32_t E,
+                         int64_t step, int32_t stage, float *out, void *stream) {
+  if (!s || !out || E < 1) return fail(MILE_ERR_INVALID, "mile_debug_noise: bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  k_debug_noise<<<E, UPD_NT, 0, (hipStream_t)stream>>>(s->ds.d, seed, particle_ids, (uint32_t)step, (uint32_t)stage, out);
+  HIP_TRY(hipGetLastError());
+  return MILE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+"""HIP path vs the CPU oracle, through the C ABI, on the same seeded inputs (-m gpu)."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+def _engine(oracle, ospec, prob, kernel='auto'):
+    from mile_amd import ModelSpec
+    from mile_amd.engine import Engine
+    spec = ModelSpec(in_features=ospec.in_features, hidden_structure=ospec.hidden_structure,
+                     activation=ospec.activation, task=ospec.task, prior=ospec.prior,
+                     prior_loc=ospec.prior_loc, prior_scale=ospec.prior_scale)
+    return Engine(spec, torch.from_numpy(prob['X']), torch.from_numpy(prob['y']), device='cuda:0',
+                  grad_kernel=kernel)
+
+
+def _relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+CASES = [
+    # in_features, hidden, activation, task, prior, N, E, kernels
+    (5, (64, 64, 64, 2), 'relu', 'regr', 'Normal', 1052, 16, ('generic', 'mfma_w64')),
+    (5, (64, 64, 64, 2), 'relu', 'regr', 'Normal', 100, 3, ('generic', 'mfma_w64')),
+    (5, (64, 64, 2), 'relu', 'regr', 'Normal', 333, 5, ('generic', 'mfma_w64')),
+    (8, (64, 2), 'relu', 'regr', 'Laplace', 64, 2, ('generic', 'mfma_w64')),
+    (5, (16, 16, 2), 'relu', 'regr', 'Normal', 1052, 12, ('generic',)),
+    (9, (24, 17, 2), 'tanh', 'regr', 'Normal', 257, 4, ('generic',)),
+    (11, (32, 7), 'sigmoid', 'classification', 'Normal', 500, 6, ('generic',)),
+    (54, (40, 40, 7), 'relu', 'classification', 'Laplace', 130, 3, ('generic',)),
+]
+
+
+@pytest.mark.parametrize('F,hs,act,task,prior,N,E,kernels', CASES)
+def test_logpost_grad_matches_oracle(oracle, F, hs, act, task, prior, N, E, kernels):
+    ospec = oracle.ModelSpec(F, hs, activation=act, task=task, prior=prior, prior_scale=0.7 if prior == 'Laplace' else 1.0)
+    prob = oracle.synthetic_problem(ospec, N, E, seed=3)
+    lp_ref, g_ref = oracle.logpost_and_grad(ospec, prob['theta0'].astype(np.float64), prob['X'], prob['y'])
+    for k in kernels:
+        eng = _engine(oracle, ospec, prob, k)
+        assert eng.grad_kernel == k
+        lp, g = eng.logpost_grad(torch.from_numpy(prob['theta0']))
+        torch.cuda.synchronize()
+        # fp32 accumulation over N rows vs fp64: tolerance 2e-5 relative to the largest entry
+        assert _relerr(lp.cpu().numpy(), lp_ref) < 2e-5, k
+        assert _relerr(g.cpu().numpy(), g_ref) < 2e-5, k
+
+
+def test_philox_noise_bits_match_oracle(oracle):
+    ospec = oracle.ModelSpec(5, (16, 16, 2))
+    prob = oracle.synthetic_problem(ospec, 64, 4)
+    eng = _engine(oracle, ospec, prob)
+    ids = np.array([7, 0, 123456, 2**31 - 1], dtype=np.int32)
+    for step, stage in ((0, 0), (5, 1), (2**32 - 1, 2)):
+        z = eng.debug_noise(seed=0xDEADBEEFCAFE, E=4, step=step, stage=stage, particle_ids=ids).cpu().numpy()
+        ref = oracle.philox_normal(0xDEADBEEFCAFE, ids, step, stage, eng.d, dtype=np.float32)
+        # integer Philox words are bit-exact; the fp32 Box-Muller differs by libm rounding only
+        assert np.abs(z - ref).max() < 2e-5
+        assert abs(z.mean()) < 0.1 and abs(z.std() - 1) < 0.1
+
+
+@pytest.mark.parametrize('kernel', ['generic', 'mfma_w64'])
+@pytest.mark.parametrize('refresh', ['O-step-O', 'step-O'])
+def test_steps_match_oracle_explicit_noise(oracle, kernel, refresh):
+    ospec = oracle.ModelSpec(5, (64, 64, 64, 2))
+    N, E, T = 300, 6, 10
+    prob = oracle.synthetic_problem(ospec, N, E, seed=11)
+    rng = np.random.default_rng(5)
+    d = ospec.n_params
+    z0 = rng.standard_normal((E, d)).astype(np.float32)
+    noise = rng.standard_normal((T, 2, E, d)).astype(np.float32)
+    f = lambda th: oracle.logpost_and_grad(ospec, th, prob['X'], prob['y'])
+    st = oracle.mclmc_init(f, prob['theta0'].astype(np.float64), z0.astype(np.float64))
+    infos = []
+    kept = []
+    for i in range(T):
+        st, info = oracle.mclmc_step(f, st, prob['eps'].astype(np.float64), prob['L'].astype(np.float64),
+                                     noise[i, 0].astype(np.float64), noise[i, 1].astype(np.float64), refresh=refresh)
+        infos.append(info)
+        if i % 3 == 0:
+            kept.append(st.position.copy())
+
+    eng = _engine(oracle, ospec, prob, kernel)
+    s0 = eng.init(torch.from_numpy(prob['theta0']), noise=torch.from_numpy(z0))
+    s1, info, samples = eng.step(s0, torch.from_numpy(prob['eps']), torch.from_numpy(prob['L']), n_steps=T,
+                                 noise=torch.from_numpy(noise), n_thinning=3, refresh=refresh)
+    torch.cuda.synchronize()
+    # fp32 state vs fp64 oracle after 10 steps (20 gradients): 1e-4 relative
+    assert _relerr(s1.position.cpu().numpy(), st.position) < 1e-4
+    assert np.abs(s1.momentum.cpu().numpy() - st.momentum).max() < 1e-4 * np.abs(st.momentum).max() + 1e-6
+    assert _relerr(s1.logdensity.cpu().numpy(), st.logdensity) < 1e-5
+    assert _relerr(s1.logdensity_grad.cpu().numpy(), st.logdensity_grad) < 1e-3
+    # unit momentum
+    assert np.abs(np.linalg.norm(s1.momentum.cpu().numpy().astype(np.float64), axis=1) - 1).max() < 1e-5
+    # info: energy_change is a difference of O(1e4) log-densities in fp32
+    dE = np.stack([i.energy_change for i in infos])
+    dK = np.stack([i.kinetic_change for i in infos])
+    assert np.abs(info.kinetic_change.cpu().numpy() - dK).max() < 1e-3 + 1e-3 * np.abs(dK).max()
+    assert np.abs(info.energy_change.cpu().numpy() - dE).max() < 5e-2
+    # thinning: integer indexing exact, kept positions are those after steps 0,3,6,9
+    assert samples.shape == (4, E, d)
+    assert _relerr(samples.cpu().numpy(), np.stack(kept)) < 1e-4
+    # the input state was not modified (functional step)
+    assert torch.equal(s0.position.cpu(), torch.from_numpy(prob['theta0']))
