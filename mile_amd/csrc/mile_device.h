@@ -53,12 +53,11 @@ __device__ __forceinline__ f32x4 philox_normal4(uint32_t quad, uint32_t pid, uin
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     const float u1 = ((float)w[2 * p] + 1.0f) * 2.3283064365386963e-10f;  // (w+1) * 2^-32 in (0,1]
-    const float u2 = (float)w[2 * p + 1] * 2.3283064365386963e-10f;
-    const float r = sqrtf(-2.0f * logf(u1));
-    float sn, cs;
-    sincosf(6.283185307179586f * u2, &sn, &cs);
-    z[2 * p] = r * cs;
-    z[2 * p + 1] = r * sn;
+    const float u2 = (float)w[2 * p + 1] * 2.3283064365386963e-10f;       // [0,1]: revolutions
+    // hardware transcendentals: v_log_f32 is log2, v_sin/v_cos take revolutions
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    z[2 * p] = r * __builtin_amdgcn_cosf(u2);
+    z[2 * p + 1] = r * __builtin_amdgcn_sinf(u2);
   }
   return z;
 }

@@ -18,6 +18,7 @@ struct GradParams {
   float *slabs;         // [E, S, d]
   float *llpart;        // [E, S]
   int32_t N, Npad, Fp, S, R;
+  int32_t dbg;          // debug knobs (MILE_DEBUG env): bit0 skip row blocks, bit1 skip staging, bit2 skip reduction
 };
 
 // Per-row log-likelihood and d/d(out).  NaN rows contribute nothing (jnp.nansum).

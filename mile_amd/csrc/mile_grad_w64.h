@@ -66,7 +66,7 @@ struct W64Layout {
   static constexpr int DOUT = XT + 32 * FP;                       // [32][2]
   static constexpr int WAVE_SZ = DOUT + 64;
   static constexpr int MAIN = WAVE0 + 4 * WAVE_SZ;
-  static constexpr int RED = 4 * 64 * W64_RS;                     // end-of-kernel reduction alias
+  static constexpr int RED = NW * 4 * 64 * W64_RS;                // end-of-kernel reduction alias
   static constexpr int TOTAL = (MAIN > RED ? MAIN : RED);
   static constexpr int BYTES = TOTAL * 4;
 };
@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p) {
   float *img = wv + LY::IMG, *xt = wv + LY::XT, *dout_l = wv + LY::DOUT;
 
   // ---- stage this particle's weights in LDS --------------------------------------
+  if (!(p.dbg & 2))
   for (int l = 1; l < NH; ++l) {
     const float *W = th + sp.w_off[l];
     for (int idx = tid; idx < 4096; idx += 256) WIMG[(l - 1) * 64 * W64_RS + (idx >> 6) * W64_RS + (idx & 63)] = W[idx];
@@ -128,7 +129,8 @@ __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p) {
   float llacc = 0.0f;
 
   const int NB = p.Npad / 32;
-  const int b0 = (int)(((long long)s * NB) / p.S), b1 = (int)(((long long)(s + 1) * NB) / p.S);
+  const int b0 = (int)(((long long)s * NB) / p.S);
+  const int b1 = (p.dbg & 1) ? b0 : (int)(((long long)(s + 1) * NB) / p.S);
 
   for (int blk = b0 + wave; blk < b1; blk += 4) {
     const int row0 = blk * 32;
@@ -318,9 +320,11 @@ __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p) {
   // ---- reduce the four waves' accumulators through LDS, write the slab -------------
   __syncthreads();  // weights and images are dead from here on; LDS is reused
   float *RED = lds;
+  if (p.dbg & 4) return;
+  // one round for all hidden->hidden matrices: RED[l][wave][in][68]
+  // D[o][i]: lane column = in-feature (32ib + j), register r = out-feature 32ob + tfeat(r,h)
 #pragma unroll
-  for (int l = 0; l < NH - 1; ++l) {
-    // D[o][i]: lane column = in-feature (32ib + j), register r = out-feature 32ob + tfeat(r,h)
+  for (int l = 0; l < NH - 1; ++l)
 #pragma unroll
     for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
@@ -329,16 +333,20 @@ __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p) {
         for (int g = 0; g < 4; ++g) {
           const f32x16 &D = dWacc[l][ob][ib];
           f32x4 v = {D[4 * g], D[4 * g + 1], D[4 * g + 2], D[4 * g + 3]};
-          *(f32x4 *)(RED + wave * 64 * W64_RS + (32 * ib + j) * W64_RS + 32 * ob + 8 * g + 4 * h) = v;
+          *(f32x4 *)(RED + (l * 4 + wave) * 64 * W64_RS + (32 * ib + j) * W64_RS + 32 * ob + 8 * g + 4 * h) = v;
         }
-    __syncthreads();
+  __syncthreads();
+#pragma unroll
+  for (int l = 0; l < NH - 1; ++l) {
     float *out = slab + sp.w_off[l + 1];
+    const float *R0 = RED + l * 4 * 64 * W64_RS;
+#pragma unroll 4
     for (int idx = tid; idx < 4096; idx += 256) {
       const int o = (idx >> 6) * W64_RS + (idx & 63);
-      out[idx] = (RED[o] + RED[64 * W64_RS + o]) + (RED[2 * 64 * W64_RS + o] + RED[3 * 64 * W64_RS + o]);
+      out[idx] = (R0[o] + R0[64 * W64_RS + o]) + (R0[2 * 64 * W64_RS + o] + R0[3 * 64 * W64_RS + o]);
     }
-    __syncthreads();
   }
+  __syncthreads();
   // small accumulators: SM[wave][k]
   constexpr int SM_B = 0;                 // biases of hidden layers [NH][64]
   constexpr int SM_W1 = SM_B + NH * 64;   // [FP][64]

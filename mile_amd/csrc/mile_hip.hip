@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -243,6 +244,45 @@ int32_t mile_get_grad_kernel(const mile_sampler *s) { return s ? resolved_kernel
 // ------------------------------------------------------------------------------------
 // grad launch
 // ------------------------------------------------------------------------------------
+static int ptr_align(const void *q) {   // alignment in floats (4, 2 or 1) of a device pointer
+  const uintptr_t a = (uintptr_t)q;
+  return (a & 15) == 0 ? 4 : ((a & 7) == 0 ? 2 : 1);
+}
+
+template <int AL, bool SDC>
+static void launch_update_al(const UpdParams &u, int E, int nk, hipStream_t st) {
+  switch (nk) {
+    case 1: k_update_fast<1, AL, SDC><<<E, UPD_NT, 0, st>>>(u); break;
+    case 2: k_update_fast<2, AL, SDC><<<E, UPD_NT, 0, st>>>(u); break;
+    case 3: k_update_fast<3, AL, SDC><<<E, UPD_NT, 0, st>>>(u); break;
+    default: k_update_fast<4, AL, SDC><<<E, UPD_NT, 0, st>>>(u); break;
+  }
+}
+
+static void launch_update(const UpdParams &u, int E, hipStream_t st) {
+  const int nqf = u.d >> 2;
+  if (nqf < 1 || nqf > UPD_NT * UPD_QMAX) {
+    if ((u.d + 3) / 4 <= UPD_NT * UPD_QMAX) k_update<true><<<E, UPD_NT, 0, st>>>(u);
+    else k_update<false><<<E, UPD_NT, 0, st>>>(u);
+    return;
+  }
+  // every row base is (pointer + e*d): vector width allowed by d and by the pointers
+  int al = (u.d % 4 == 0) ? 4 : ((u.d % 2 == 0) ? 2 : 1);
+  const void *ptrs[] = {u.x, u.u, u.g, u.slabs, u.sdc, u.zA, u.zB, u.out_sample};
+  for (const void *q : ptrs)
+    if (q) al = std::min(al, ptr_align(q));
+  const int nk = (nqf + UPD_NT - 1) / UPD_NT;
+  if (u.sdc) {
+    if (al == 4) launch_update_al<4, true>(u, E, nk, st);
+    else if (al == 2) launch_update_al<2, true>(u, E, nk, st);
+    else launch_update_al<1, true>(u, E, nk, st);
+  } else {
+    if (al == 4) launch_update_al<4, false>(u, E, nk, st);
+    else if (al == 2) launch_update_al<2, false>(u, E, nk, st);
+    else launch_update_al<1, false>(u, E, nk, st);
+  }
+}
+
 template <int NH, int FQ>
 static hipError_t launch_w64(const GradParams &gp, int E, hipStream_t st) {
   using LY = W64Layout<NH, FQ>;
@@ -270,6 +310,7 @@ static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t s
   gp.X = s->X; gp.Xp = s->Xp; gp.y = s->y;
   gp.slabs = s->slabs; gp.llpart = s->llpart;
   gp.N = s->N; gp.Npad = s->Npad; gp.Fp = s->Fp; gp.S = S; gp.R = generic_R(s->ds);
+  { const char *dv = getenv("MILE_DEBUG"); gp.dbg = dv ? atoi(dv) : 0; }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (s->timing) {
     if (s->ev_used + 2 > s->ev.size()) {
@@ -359,7 +400,7 @@ int32_t mile_logpost_grad(mile_sampler *s, const float *theta, int32_t E, float 
   int rc = launch_grad(s, theta, E, st);
   if (rc) return rc;
   const int S = choose_S(s, E, resolved_kernel(s));
-  k_finalize<<<E, UPD_NT, 0, st>>>(s->ds.d, S, s->ds.prior, s->ds.prior_loc, s->ds.prior_scale, theta,
+  k_finalize<<<E, AUX_NT, 0, st>>>(s->ds.d, S, s->ds.prior, s->ds.prior_loc, s->ds.prior_scale, theta,
                                    s->slabs, s->llpart, grad, logp);
   HIP_TRY(hipGetLastError());
   return MILE_OK;
@@ -374,7 +415,7 @@ int32_t mile_init(mile_sampler *s, mile_state *state, const float *noise, uint64
   hipStream_t st = (hipStream_t)stream;
   int rc = mile_logpost_grad(s, state->position, E, state->logdensity, state->logdensity_grad, stream);
   if (rc) return rc;
-  k_init_momentum<<<E, UPD_NT, 0, st>>>(s->ds.d, noise, seed, particle_ids, state->momentum);
+  k_init_momentum<<<E, AUX_NT, 0, st>>>(s->ds.d, noise, seed, particle_ids, state->momentum);
   HIP_TRY(hipGetLastError());
   return MILE_OK;
 }
@@ -418,7 +459,7 @@ int32_t mile_step(mile_sampler *s, mile_state *state, const mile_step_args *a, v
       u.flags = UPD_START | UPD_B2 | UPD_A | (oso ? UPD_OB : 0);
       u.zB = noise_at(i, 0); u.stepB = (uint32_t)gstep; u.stageB = 0; u.hB = 0.5f;
       u.coef_b2 = b1; u.coef_a = 0.5f;
-      k_update<<<E, UPD_NT, 0, st>>>(u);
+      launch_update(u, E, st);
     }
     int rc = launch_grad(s, state->position, E, st);
     if (rc) return rc;
@@ -426,7 +467,7 @@ int32_t mile_step(mile_sampler *s, mile_state *state, const mile_step_args *a, v
       UpdParams u = up;
       u.flags = UPD_FROM_SLABS | UPD_B1 | UPD_A;
       u.coef_b1 = b2; u.coef_a = 0.5f;
-      k_update<<<E, UPD_NT, 0, st>>>(u);
+      launch_update(u, E, st);
     }
     rc = launch_grad(s, state->position, E, st);
     if (rc) return rc;
@@ -446,7 +487,7 @@ int32_t mile_step(mile_sampler *s, mile_state *state, const mile_step_args *a, v
         u.out_sample = a->out_samples + (size_t)kept * Ed;
         ++kept;
       }
-      k_update<<<E, UPD_NT, 0, st>>>(u);
+      launch_update(u, E, st);
     }
   }
   HIP_TRY(hipGetLastError());
@@ -457,7 +498,7 @@ int32_t mile_debug_noise(mile_sampler *s, uint64_t seed, const int32_t *particle
                          int64_t step, int32_t stage, float *out, void *stream) {
   if (!s || !out || E < 1) return fail(MILE_ERR_INVALID, "mile_debug_noise: bad argument");
   HIP_TRY(hipSetDevice(s->device));
-  k_debug_noise<<<E, UPD_NT, 0, (hipStream_t)stream>>>(s->ds.d, seed, particle_ids, (uint32_t)step, (uint32_t)stage, out);
+  k_debug_noise<<<E, AUX_NT, 0, (hipStream_t)stream>>>(s->ds.d, seed, particle_ids, (uint32_t)step, (uint32_t)stage, out);
   HIP_TRY(hipGetLastError());
   return MILE_OK;
 }

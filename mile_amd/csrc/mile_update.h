@@ -44,48 +44,60 @@ struct UpdParams {
   float *out_info;               // [E, 3] or NULL
 };
 
+// B / O chain on the coefficients of {u, e, zA, zB}; norms and projections come from the
+// Gram matrix M.  fp32 with expm1f/log1pf: the inputs (dot products) are fp32 sums anyway
+// and every cancellation-prone expression is written in its stable form.
 struct Chain {
-  double M[4][4];
-  double c[4];
-  __device__ double norm() const {
-    double s = 0.0;
+  float M[4][4];
+  float c[4];
+  __device__ __forceinline__ float norm() const {
+    float s = 0.0f;
+#pragma unroll
     for (int a = 0; a < 4; ++a)
-      for (int b = 0; b < 4; ++b) s += c[a] * M[a][b] * c[b];
-    return sqrt(s);
-  }
-  __device__ void normalize() {
-    const double n = norm();
-    if (n > 1e-13)  // blackjax normalized_flatten_array tolerance
-      for (int a = 0; a < 4; ++a) c[a] /= n;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) s = fmaf(c[a] * M[a][b], c[b], s);
+    return sqrtf(s);
   }
   // esh_dynamics_momentum_update_one_step (A.2); returns the kinetic energy change
-  __device__ double B(double eps, double coef, double gnorm, int d) {
-    double ue = 0.0;
-    for (int a = 0; a < 4; ++a) ue += c[a] * M[a][1];
-    const double delta = eps * coef * gnorm / (double)(d - 1);
-    const double zeta = exp(-delta);
-    const double beta = (1.0 - zeta) * (1.0 + zeta + ue * (1.0 - zeta));
-    for (int a = 0; a < 4; ++a) c[a] *= 2.0 * zeta;
+  __device__ __forceinline__ float B(float eps, float coef, float gnorm, int d) {
+    float ue = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) ue = fmaf(c[a], M[a][1], ue);
+    const float delta = eps * coef * gnorm / (float)(d - 1);
+    const float omz = -expm1f(-delta);            // 1 - zeta
+    const float zeta = 1.0f - omz;
+    const float beta = omz * (1.0f + zeta + ue * omz);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) c[a] *= 2.0f * zeta;
     c[1] += beta;
-    normalize();
-    // (d-1) (delta - ln2 + ln(1 + ue + (1-ue) zeta^2)), written without the cancellation
-    return (double)(d - 1) * (delta + log1p(0.5 * (1.0 - ue) * expm1(-2.0 * delta)));
+    const float n = norm();
+    if (n > 1e-13f)                               // blackjax normalized_flatten_array tolerance
+#pragma unroll
+      for (int a = 0; a < 4; ++a) c[a] /= n;
+    // (d-1) (delta - ln2 + ln(1 + ue + (1-ue) zeta^2)) without the cancellation
+    return (float)(d - 1) * (delta + log1pf(0.5f * (1.0f - ue) * expm1f(-2.0f * delta)));
   }
   // partially_refresh_momentum (A.5)
-  __device__ void O(int k, double hstep, double L, int d) {
-    const double nu = sqrt(expm1(2.0 * hstep / L) / (double)d);
+  __device__ __forceinline__ void O(int k, float hstep, float L, int d) {
+    const float nu = sqrtf(expm1f(2.0f * hstep / L) / (float)d);
     c[k] += nu;
-    const double n = norm();
+    const float n = norm();
+#pragma unroll
     for (int a = 0; a < 4; ++a) c[a] /= n;
   }
 };
 
-#define UPD_NT 256
+#define UPD_NT 1024
+#define UPD_NW (UPD_NT / 64)
 #define UPD_NSUM 11
+#define UPD_QMAX 4   // quads a thread keeps in registers between the passes (d <= 16384)
 
+// CACHED: every thread keeps its <= UPD_QMAX quads of (x, u, g~, zA, zB) in registers between
+// pass 1 and pass 2, so state is read once, noise is generated once and written once.
+template <bool CACHED>
 __global__ __launch_bounds__(UPD_NT) void k_update(const UpdParams p) {
-  __shared__ float red[UPD_NT / 64][UPD_NSUM];
-  __shared__ float bc[8];
+  __shared__ float red[UPD_NW][UPD_NSUM + 1];
+  __shared__ float tot[UPD_NSUM + 1];
   const int tid = threadIdx.x, e = blockIdx.x, d = p.d;
   const size_t base = (size_t)e * d;
   const int nq = (d + 3) >> 2;
@@ -93,18 +105,21 @@ __global__ __launch_bounds__(UPD_NT) void k_update(const UpdParams p) {
   const bool useA = p.flags & UPD_OA, useB = p.flags & UPD_OB;
   const uint32_t pid = p.pids ? (uint32_t)p.pids[e] : (uint32_t)e;
   const float *sl = p.slabs + (size_t)e * p.S * d;
+  constexpr int NK = CACHED ? UPD_QMAX : 1;
+  f32x4 cx[NK], cu[NK], cg[NK], ca[NK], cb[NK];
 
   // ---- pass 1 ----------------------------------------------------------------------
   float sm[UPD_NSUM];
 #pragma unroll
   for (int k = 0; k < UPD_NSUM; ++k) sm[k] = 0.0f;
-  for (int q = tid; q < nq; q += UPD_NT) {
-    f32x4 za = {0, 0, 0, 0}, zb = {0, 0, 0, 0};
-    if (useA && !p.zA) za = philox_normal4(q, pid, p.stepA, p.stageA, p.seed);
-    if (useB && !p.zB) zb = philox_normal4(q, pid, p.stepB, p.stageB, p.seed);
+  auto pass1 = [&](int q, f32x4 &X, f32x4 &U, f32x4 &G, f32x4 &A, f32x4 &B) {
+    A = f32x4{0, 0, 0, 0}; B = f32x4{0, 0, 0, 0};
+    if (useA && !p.zA) A = philox_normal4(q, pid, p.stepA, p.stageA, p.seed);
+    if (useB && !p.zB) B = philox_normal4(q, pid, p.stepB, p.stageB, p.seed);
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int i = 4 * q + m;
+      X[m] = U[m] = G[m] = 0.0f;
       if (i < d) {
         float gi;
         const float xi = p.x[base + i];
@@ -114,10 +129,10 @@ __global__ __launch_bounds__(UPD_NT) void k_update(const UpdParams p) {
           const float t = (xi - p.prior_loc) / p.prior_scale;
           if (p.prior == MILE_PRIOR_NORMAL) {
             gi -= t / p.prior_scale;
-            sm[10] += -0.5f * t * t;
+            sm[10] = fmaf(-0.5f * t, t, sm[10]);
           } else {
             gi -= (t > 0.0f ? 1.0f : (t < 0.0f ? -1.0f : 0.0f)) / p.prior_scale;
-            sm[10] += -fabsf(t);
+            sm[10] -= fabsf(t);
           }
           p.g[base + i] = gi;
         } else {
@@ -125,14 +140,27 @@ __global__ __launch_bounds__(UPD_NT) void k_update(const UpdParams p) {
         }
         const float gs = p.sdc ? gi * p.sdc[base + i] : gi;
         const float ui = p.u[base + i];
-        const float a = useA ? (p.zA ? p.zA[base + i] : za[m]) : 0.0f;
-        const float b = useB ? (p.zB ? p.zB[base + i] : zb[m]) : 0.0f;
+        if (useA && p.zA) A[m] = p.zA[base + i];
+        if (useB && p.zB) B[m] = p.zB[base + i];
+        const float a = A[m], b = B[m];
+        X[m] = xi; U[m] = ui; G[m] = gs;
         sm[0] = fmaf(ui, ui, sm[0]); sm[1] = fmaf(ui, gs, sm[1]); sm[2] = fmaf(gs, gs, sm[2]);
         sm[3] = fmaf(ui, a, sm[3]); sm[4] = fmaf(gs, a, sm[4]); sm[5] = fmaf(a, a, sm[5]);
         sm[6] = fmaf(ui, b, sm[6]); sm[7] = fmaf(gs, b, sm[7]); sm[8] = fmaf(b, b, sm[8]);
         sm[9] = fmaf(a, b, sm[9]);
+      } else {
+        A[m] = B[m] = 0.0f;
       }
     }
+  };
+  if (CACHED) {
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int q = tid + k * UPD_NT;
+      if (q < nq) pass1(q, cx[k], cu[k], cg[k], ca[k], cb[k]);
+    }
+  } else {
+    for (int q = tid; q < nq; q += UPD_NT) pass1(q, cx[0], cu[0], cg[0], ca[0], cb[0]);
   }
 #pragma unroll
   for (int k = 0; k < UPD_NSUM; ++k) sm[k] = wave_sum(sm[k]);
@@ -140,102 +168,360 @@ __global__ __launch_bounds__(UPD_NT) void k_update(const UpdParams p) {
 #pragma unroll
     for (int k = 0; k < UPD_NSUM; ++k) red[tid >> 6][k] = sm[k];
   __syncthreads();
-
-  // ---- scalar chain (every thread, redundantly, in fp64) ---------------------------
-  double S[UPD_NSUM];
+  if (tid < UPD_NSUM) {
+    float t = 0.0f;
 #pragma unroll
-  for (int k = 0; k < UPD_NSUM; ++k) {
-    double t = 0.0;
-    for (int w = 0; w < UPD_NT / 64; ++w) t += (double)red[w][k];
-    S[k] = t;
+    for (int w = 0; w < UPD_NW; ++w) t += red[w][tid];
+    tot[tid] = t;
   }
-  const double eps = p.eps[e], L = p.L[e];
-  double logp_now;
+  __syncthreads();
+
+  // ---- scalar chain (every thread, redundantly) -------------------------------------
+  float S[UPD_NSUM];
+#pragma unroll
+  for (int k = 0; k < UPD_NSUM; ++k) S[k] = tot[k];
+  const float eps = p.eps[e], L = p.L[e];
+  float logp_now;
   if (from_slabs) {
-    double ll = 0.0;
-    for (int s = 0; s < p.S; ++s) ll += (double)p.llpart[(size_t)e * p.S + s];
-    const double cst = p.prior == MILE_PRIOR_NORMAL
-                           ? -(double)d * (log((double)p.prior_scale) + 0.91893853320467274)
-                           : -(double)d * log(2.0 * (double)p.prior_scale);
-    logp_now = ll + S[10] + cst;
+    float ll = 0.0f;
+    for (int s = 0; s < p.S; ++s) ll += p.llpart[(size_t)e * p.S + s];
+    const float cst = p.prior == MILE_PRIOR_NORMAL ? -(float)d * (logf(p.prior_scale) + 0.91893853320467274f)
+                                                   : -(float)d * logf(2.0f * p.prior_scale);
+    logp_now = ll + (S[10] + cst);
   } else {
     logp_now = p.logp[e];
   }
-  const double gn = S[2] > 0.0 ? sqrt(S[2]) : 1.0;
+  const float gn = S[2] > 0.0f ? sqrtf(S[2]) : 1.0f;
+  const float ign = 1.0f / gn;
   Chain ch;
-  ch.M[0][0] = S[0]; ch.M[0][1] = S[1] / gn; ch.M[0][2] = S[3]; ch.M[0][3] = S[6];
-  ch.M[1][1] = 1.0;  ch.M[1][2] = S[4] / gn; ch.M[1][3] = S[7] / gn;
+  ch.M[0][0] = S[0]; ch.M[0][1] = S[1] * ign; ch.M[0][2] = S[3]; ch.M[0][3] = S[6];
+  ch.M[1][1] = 1.0f; ch.M[1][2] = S[4] * ign; ch.M[1][3] = S[7] * ign;
   ch.M[2][2] = S[5]; ch.M[2][3] = S[9];
   ch.M[3][3] = S[8];
+#pragma unroll
   for (int a = 0; a < 4; ++a)
-    for (int b = 0; b < a; ++b) ch.M[a][b] = ch.M[b][a];
-  ch.c[0] = 1.0; ch.c[1] = ch.c[2] = ch.c[3] = 0.0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (b < a) ch.M[a][b] = ch.M[b][a];
+  ch.c[0] = 1.0f; ch.c[1] = ch.c[2] = ch.c[3] = 0.0f;
 
-  double dk = (p.flags & UPD_START) ? 0.0 : (double)p.dK[e];
-  double lold = (p.flags & UPD_START) ? logp_now : (double)p.lold[e];
+  float dk = (p.flags & UPD_START) ? 0.0f : p.dK[e];
+  float lold = (p.flags & UPD_START) ? logp_now : p.lold[e];
   if (p.flags & UPD_B1) dk += ch.B(eps, p.coef_b1, gn, d);
-  if (p.flags & UPD_OA) ch.O(2, (double)p.hA * eps, L, d);
-  double info_dk = 0.0, info_de = 0.0;
+  if (p.flags & UPD_OA) ch.O(2, p.hA * eps, L, d);
+  float info_dk = 0.0f, info_de = 0.0f;
   if (p.flags & UPD_RECORD) {
     info_dk = dk;
-    info_de = dk - logp_now + lold;
-    dk = 0.0;
+    info_de = dk - (logp_now - lold);
+    dk = 0.0f;
     lold = logp_now;
   }
-  if (p.flags & UPD_OB) ch.O(3, (double)p.hB * eps, L, d);
+  if (p.flags & UPD_OB) ch.O(3, p.hB * eps, L, d);
   if (p.flags & UPD_B2) dk += ch.B(eps, p.coef_b2, gn, d);
   __syncthreads();  // all threads have read dK/lold/logp before thread 0 rewrites them
   if (tid == 0) {
-    p.dK[e] = (float)dk;
-    p.lold[e] = (float)lold;
-    if (from_slabs) p.logp[e] = (float)logp_now;
+    p.dK[e] = dk;
+    p.lold[e] = lold;
+    if (from_slabs) p.logp[e] = logp_now;
     if ((p.flags & UPD_RECORD) && p.out_info) {
-      p.out_info[3 * e + 0] = (float)logp_now;
-      p.out_info[3 * e + 1] = (float)info_dk;
-      p.out_info[3 * e + 2] = (float)info_de;
+      p.out_info[3 * e + 0] = logp_now;
+      p.out_info[3 * e + 1] = info_dk;
+      p.out_info[3 * e + 2] = info_de;
     }
   }
   const bool any_op = p.flags & (UPD_B1 | UPD_OA | UPD_OB | UPD_B2);
   if (!any_op && !(p.flags & UPD_A) && !p.out_sample) return;
 
   // ---- pass 2 ----------------------------------------------------------------------
-  const float c0 = (float)ch.c[0], c1 = (float)(ch.c[1] / gn), c2 = (float)ch.c[2], c3 = (float)ch.c[3];
-  const float ea = (float)(eps * (double)p.coef_a);
-  for (int q = tid; q < nq; q += UPD_NT) {
-    f32x4 za = {0, 0, 0, 0}, zb = {0, 0, 0, 0};
-    if (useA && !p.zA) za = philox_normal4(q, pid, p.stepA, p.stageA, p.seed);
-    if (useB && !p.zB) zb = philox_normal4(q, pid, p.stepB, p.stageB, p.seed);
+  const float c0 = ch.c[0], c1 = ch.c[1] * ign, c2 = ch.c[2], c3 = ch.c[3];
+  const float ea = eps * p.coef_a;
+  auto pass2 = [&](int q, const f32x4 &X, const f32x4 &U, const f32x4 &G, const f32x4 &A, const f32x4 &B) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int i = 4 * q + m;
       if (i < d) {
         const float sd = p.sdc ? p.sdc[base + i] : 1.0f;
-        const float gs = p.g[base + i] * sd;
-        const float a = useA ? (p.zA ? p.zA[base + i] : za[m]) : 0.0f;
-        const float b = useB ? (p.zB ? p.zB[base + i] : zb[m]) : 0.0f;
-        float v = p.u[base + i];
+        float v = U[m];
         if (any_op) {
-          v = fmaf(c0, v, fmaf(c1, gs, fmaf(c2, a, c3 * b)));
+          v = fmaf(c0, v, fmaf(c1, G[m], fmaf(c2, A[m], c3 * B[m])));
           p.u[base + i] = v;
         }
-        const float xi = p.x[base + i];
-        if (p.out_sample) p.out_sample[base + i] = xi;
-        if (p.flags & UPD_A) p.x[base + i] = fmaf(ea * sd, v, xi);
+        if (p.out_sample) p.out_sample[base + i] = X[m];
+        if (p.flags & UPD_A) p.x[base + i] = fmaf(ea * sd, v, X[m]);
       }
+    }
+  };
+  if (CACHED) {
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int q = tid + k * UPD_NT;
+      if (q < nq) pass2(q, cx[k], cu[k], cg[k], ca[k], cb[k]);
+    }
+  } else {
+    for (int q = tid; q < nq; q += UPD_NT) {
+      f32x4 X, U, G, A = {0, 0, 0, 0}, B = {0, 0, 0, 0};
+      if (useA && !p.zA) A = philox_normal4(q, pid, p.stepA, p.stageA, p.seed);
+      if (useB && !p.zB) B = philox_normal4(q, pid, p.stepB, p.stageB, p.seed);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int i = 4 * q + m;
+        X[m] = U[m] = G[m] = 0.0f;
+        if (i < d) {
+          X[m] = p.x[base + i]; U[m] = p.u[base + i];
+          G[m] = p.g[base + i] * (p.sdc ? p.sdc[base + i] : 1.0f);
+          if (useA && p.zA) A[m] = p.zA[base + i];
+          if (useB && p.zB) B[m] = p.zB[base + i];
+        }
+      }
+      pass2(q, X, U, G, A, B);
     }
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Fast path of k_update for d <= 4*UPD_NT*UPD_QMAX: branch-free, all loads of a thread are
+// issued back to back (clamped addresses + masks instead of bounds branches) as AL-float
+// vectors, state and noise stay in registers between the two passes.
+// NK = quads per thread, AL = guaranteed alignment (floats) of every row base.
+// ---------------------------------------------------------------------------------------
+template <int AL>
+__device__ __forceinline__ f32x4 ld4(const float *q) {
+  if constexpr (AL == 4) {
+    return *(const f32x4 *)q;
+  } else if constexpr (AL == 2) {
+    const f32x2 a = *(const f32x2 *)q, b = *(const f32x2 *)(q + 2);
+    return f32x4{a[0], a[1], b[0], b[1]};
+  } else {
+    return f32x4{q[0], q[1], q[2], q[3]};
+  }
+}
+template <int AL>
+__device__ __forceinline__ void st4(float *q, const f32x4 v) {
+  if constexpr (AL == 4) {
+    *(f32x4 *)q = v;
+  } else if constexpr (AL == 2) {
+    *(f32x2 *)q = f32x2{v[0], v[1]};
+    *(f32x2 *)(q + 2) = f32x2{v[2], v[3]};
+  } else {
+    q[0] = v[0]; q[1] = v[1]; q[2] = v[2]; q[3] = v[3];
+  }
+}
+
+template <int NK, int AL, bool SDC>
+__global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
+  __shared__ float red[UPD_NW][UPD_NSUM + 1];
+  __shared__ float tot[UPD_NSUM + 1];
+  const int tid = threadIdx.x, e = blockIdx.x, d = p.d;
+  const size_t base = (size_t)e * d;
+  const int nqf = d >> 2;            // full quads
+  const int ntail = d & 3;           // leftover elements, handled by threads 0..ntail-1
+  const bool from_slabs = p.flags & UPD_FROM_SLABS;
+  const bool useA = p.flags & UPD_OA, useB = p.flags & UPD_OB;
+  const bool explA = useA && p.zA, explB = useB && p.zB;
+  const uint32_t pid = p.pids ? (uint32_t)p.pids[e] : (uint32_t)e;
+  const float *sl = p.slabs + (size_t)e * p.S * d;
+  const float ips = 1.0f / p.prior_scale;
+  const bool normal = p.prior == MILE_PRIOR_NORMAL;
+
+  f32x4 cx[NK], cu[NK], cg[NK], ca[NK], cb[NK], csd[SDC ? NK : 1];
+  // ---- pass 1: loads -----------------------------------------------------------------
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int q = tid + k * UPD_NT;
+    const bool valid = q < nqf;
+    const size_t o = base + 4 * (size_t)(valid ? q : 0);
+    cx[k] = ld4<AL>(p.x + o);
+    cu[k] = ld4<AL>(p.u + o);
+    if (from_slabs) {
+      f32x4 g = ld4<AL>(sl + (o - base));
+      for (int s = 1; s < p.S; ++s) g += ld4<AL>(sl + (size_t)s * d + (o - base));
+      cg[k] = g;
+    } else {
+      cg[k] = ld4<AL>(p.g + o);
+    }
+    if constexpr (SDC) csd[k] = ld4<AL>(p.sdc + o);
+    ca[k] = explA ? ld4<AL>(p.zA + o) : f32x4{0, 0, 0, 0};
+    cb[k] = explB ? ld4<AL>(p.zB + o) : f32x4{0, 0, 0, 0};
+  }
+  // tail element (at most 3 per particle): thread t < ntail owns element 4*nqf + t
+  const bool has_tail = tid < ntail;
+  const size_t to = base + 4 * (size_t)nqf + (has_tail ? tid : 0);
+  float tx = 0, tu = 0, tg = 0, ta = 0, tb = 0, tsd = 1.0f;
+  if (ntail) {
+    const size_t tc = has_tail ? to : base;
+    tx = p.x[tc]; tu = p.u[tc];
+    if (from_slabs) { tg = 0.0f; for (int s = 0; s < p.S; ++s) tg += sl[(size_t)s * d + (tc - base)]; }
+    else tg = p.g[tc];
+    if (SDC) tsd = p.sdc[tc];
+    if (explA) ta = p.zA[tc];
+    if (explB) tb = p.zB[tc];
+  }
+  // ---- pass 1: noise + sums ------------------------------------------------------------
+  float sm[UPD_NSUM];
+#pragma unroll
+  for (int k = 0; k < UPD_NSUM; ++k) sm[k] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int q = tid + k * UPD_NT;
+    if (useA && !p.zA) ca[k] = philox_normal4(q, pid, p.stepA, p.stageA, p.seed);
+    if (useB && !p.zB) cb[k] = philox_normal4(q, pid, p.stepB, p.stageB, p.seed);
+    const float mk = q < nqf ? 1.0f : 0.0f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      float gi = cg[k][m];
+      const float xi = cx[k][m];
+      if (from_slabs) {
+        const float t = (xi - p.prior_loc) * ips;
+        if (normal) { gi = fmaf(-t, ips, gi); sm[10] = fmaf(-0.5f * mk * t, t, sm[10]); }
+        else { gi -= (t > 0.0f ? ips : (t < 0.0f ? -ips : 0.0f)); sm[10] -= mk * fabsf(t); }
+      }
+      cg[k][m] = gi;                       // un-preconditioned gradient (stored below)
+      const float gs = (SDC ? gi * csd[k][m] : gi) * mk;
+      const float ui = cu[k][m] * mk, a = ca[k][m] * mk, b = cb[k][m] * mk;
+      ca[k][m] = a; cb[k][m] = b;
+      sm[0] = fmaf(ui, ui, sm[0]); sm[1] = fmaf(ui, gs, sm[1]); sm[2] = fmaf(gs, gs, sm[2]);
+      sm[3] = fmaf(ui, a, sm[3]); sm[4] = fmaf(gs, a, sm[4]); sm[5] = fmaf(a, a, sm[5]);
+      sm[6] = fmaf(ui, b, sm[6]); sm[7] = fmaf(gs, b, sm[7]); sm[8] = fmaf(b, b, sm[8]);
+      sm[9] = fmaf(a, b, sm[9]);
+    }
+    if (from_slabs && q < nqf) st4<AL>(p.g + base + 4 * (size_t)q, cg[k]);
+    if constexpr (SDC) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) cg[k][m] *= csd[k][m];   // keep g~ = g*s for pass 2
+    }
+  }
+  if (ntail) {
+    f32x4 za = {0, 0, 0, 0}, zb = {0, 0, 0, 0};
+    if (useA && !p.zA) za = philox_normal4(nqf, pid, p.stepA, p.stageA, p.seed);
+    if (useB && !p.zB) zb = philox_normal4(nqf, pid, p.stepB, p.stageB, p.seed);
+    const int t = has_tail ? tid : 0;
+    if (useA && !p.zA) ta = za[t];
+    if (useB && !p.zB) tb = zb[t];
+    const float mk = has_tail ? 1.0f : 0.0f;
+    if (from_slabs) {
+      const float tt = (tx - p.prior_loc) * ips;
+      if (normal) { tg = fmaf(-tt, ips, tg); sm[10] = fmaf(-0.5f * mk * tt, tt, sm[10]); }
+      else { tg -= (tt > 0.0f ? ips : (tt < 0.0f ? -ips : 0.0f)); sm[10] -= mk * fabsf(tt); }
+      if (has_tail) p.g[to] = tg;
+    }
+    tg *= tsd;
+    const float gs = tg * mk, ui = tu * mk;
+    ta *= mk; tb *= mk;
+    sm[0] = fmaf(ui, ui, sm[0]); sm[1] = fmaf(ui, gs, sm[1]); sm[2] = fmaf(gs, gs, sm[2]);
+    sm[3] = fmaf(ui, ta, sm[3]); sm[4] = fmaf(gs, ta, sm[4]); sm[5] = fmaf(ta, ta, sm[5]);
+    sm[6] = fmaf(ui, tb, sm[6]); sm[7] = fmaf(gs, tb, sm[7]); sm[8] = fmaf(tb, tb, sm[8]);
+    sm[9] = fmaf(ta, tb, sm[9]);
+  }
+#pragma unroll
+  for (int k = 0; k < UPD_NSUM; ++k) sm[k] = wave_sum(sm[k]);
+  if ((tid & 63) == 0)
+#pragma unroll
+    for (int k = 0; k < UPD_NSUM; ++k) red[tid >> 6][k] = sm[k];
+  __syncthreads();
+  if (tid < UPD_NSUM) {
+    float t = 0.0f;
+#pragma unroll
+    for (int w = 0; w < UPD_NW; ++w) t += red[w][tid];
+    tot[tid] = t;
+  }
+  __syncthreads();
+
+  // ---- scalar chain ---------------------------------------------------------------------
+  float S[UPD_NSUM];
+#pragma unroll
+  for (int k = 0; k < UPD_NSUM; ++k) S[k] = tot[k];
+  const float eps = p.eps[e], L = p.L[e];
+  float logp_now;
+  if (from_slabs) {
+    float ll = 0.0f;
+    for (int s = 0; s < p.S; ++s) ll += p.llpart[(size_t)e * p.S + s];
+    const float cst = normal ? -(float)d * (logf(p.prior_scale) + 0.91893853320467274f)
+                             : -(float)d * logf(2.0f * p.prior_scale);
+    logp_now = ll + (S[10] + cst);
+  } else {
+    logp_now = p.logp[e];
+  }
+  const float gn = S[2] > 0.0f ? sqrtf(S[2]) : 1.0f;
+  const float ign = 1.0f / gn;
+  Chain ch;
+  ch.M[0][0] = S[0]; ch.M[0][1] = S[1] * ign; ch.M[0][2] = S[3]; ch.M[0][3] = S[6];
+  ch.M[1][1] = 1.0f; ch.M[1][2] = S[4] * ign; ch.M[1][3] = S[7] * ign;
+  ch.M[2][2] = S[5]; ch.M[2][3] = S[9];
+  ch.M[3][3] = S[8];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (b < a) ch.M[a][b] = ch.M[b][a];
+  ch.c[0] = 1.0f; ch.c[1] = ch.c[2] = ch.c[3] = 0.0f;
+  float dk = (p.flags & UPD_START) ? 0.0f : p.dK[e];
+  float lold = (p.flags & UPD_START) ? logp_now : p.lold[e];
+  if (p.flags & UPD_B1) dk += ch.B(eps, p.coef_b1, gn, d);
+  if (p.flags & UPD_OA) ch.O(2, p.hA * eps, L, d);
+  float info_dk = 0.0f, info_de = 0.0f;
+  if (p.flags & UPD_RECORD) {
+    info_dk = dk;
+    info_de = dk - (logp_now - lold);
+    dk = 0.0f;
+    lold = logp_now;
+  }
+  if (p.flags & UPD_OB) ch.O(3, p.hB * eps, L, d);
+  if (p.flags & UPD_B2) dk += ch.B(eps, p.coef_b2, gn, d);
+  __syncthreads();
+  if (tid == 0) {
+    p.dK[e] = dk;
+    p.lold[e] = lold;
+    if (from_slabs) p.logp[e] = logp_now;
+    if ((p.flags & UPD_RECORD) && p.out_info) {
+      p.out_info[3 * e + 0] = logp_now;
+      p.out_info[3 * e + 1] = info_dk;
+      p.out_info[3 * e + 2] = info_de;
+    }
+  }
+  // ---- pass 2 (from registers) ------------------------------------------------------------
+  const bool any_op = p.flags & (UPD_B1 | UPD_OA | UPD_OB | UPD_B2);
+  const bool doA = p.flags & UPD_A;
+  const float c0 = ch.c[0], c1 = ch.c[1] * ign, c2 = ch.c[2], c3 = ch.c[3];
+  const float ea = eps * p.coef_a;
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int q = tid + k * UPD_NT;
+    if (q < nqf) {
+      const size_t o = base + 4 * (size_t)q;
+      f32x4 v = cu[k];
+      if (any_op) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) v[m] = fmaf(c0, cu[k][m], fmaf(c1, cg[k][m], fmaf(c2, ca[k][m], c3 * cb[k][m])));
+        st4<AL>(p.u + o, v);
+      }
+      if (p.out_sample) st4<AL>(p.out_sample + o, cx[k]);
+      if (doA) {
+        f32x4 xn;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xn[m] = fmaf(SDC ? ea * csd[k][m] : ea, v[m], cx[k][m]);
+        st4<AL>(p.x + o, xn);
+      }
+    }
+  }
+  if (has_tail) {
+    float v = tu;
+    if (any_op) { v = fmaf(c0, tu, fmaf(c1, tg, fmaf(c2, ta, c3 * tb))); p.u[to] = v; }
+    if (p.out_sample) p.out_sample[to] = tx;
+    if (doA) p.x[to] = fmaf(ea * tsd, v, tx);
+  }
+}
+
+#define AUX_NT 256
 // g = sum_s slab + grad log prior;  logp = sum_s llpart + log prior.   (mile_logpost_grad)
-__global__ __launch_bounds__(UPD_NT) void k_finalize(int d, int S, int prior, float loc, float scale,
+__global__ __launch_bounds__(AUX_NT) void k_finalize(int d, int S, int prior, float loc, float scale,
                                                      const float *theta, const float *slabs,
                                                      const float *llpart, float *grad, float *logp) {
-  __shared__ float red[UPD_NT / 64];
+  __shared__ float red[AUX_NT / 64];
   const int tid = threadIdx.x, e = blockIdx.x;
   const size_t base = (size_t)e * d;
   const float *sl = slabs + (size_t)e * S * d;
   float pv = 0.0f;
-  for (int i = tid; i < d; i += UPD_NT) {
+  for (int i = tid; i < d; i += AUX_NT) {
     float gi = 0.0f;
     for (int s = 0; s < S; ++s) gi += sl[(size_t)s * d + i];
     const float t = (theta[base + i] - loc) / scale;
@@ -248,7 +534,7 @@ __global__ __launch_bounds__(UPD_NT) void k_finalize(int d, int S, int prior, fl
   __syncthreads();
   if (tid == 0) {
     double t = 0.0;
-    for (int w = 0; w < UPD_NT / 64; ++w) t += (double)red[w];
+    for (int w = 0; w < AUX_NT / 64; ++w) t += (double)red[w];
     for (int s = 0; s < S; ++s) t += (double)llpart[(size_t)e * S + s];
     t += prior == MILE_PRIOR_NORMAL ? -(double)d * (log((double)scale) + 0.91893853320467274)
                                     : -(double)d * log(2.0 * (double)scale);
@@ -257,15 +543,15 @@ __global__ __launch_bounds__(UPD_NT) void k_finalize(int d, int S, int prior, fl
 }
 
 // momentum = z / |z|  (generate_unit_vector of blackjax.mcmc.mclmc.init, A.1)
-__global__ __launch_bounds__(UPD_NT) void k_init_momentum(int d, const float *z, uint64_t seed,
+__global__ __launch_bounds__(AUX_NT) void k_init_momentum(int d, const float *z, uint64_t seed,
                                                           const int32_t *pids, float *u) {
-  __shared__ float red[UPD_NT / 64];
+  __shared__ float red[AUX_NT / 64];
   const int tid = threadIdx.x, e = blockIdx.x;
   const size_t base = (size_t)e * d;
   const uint32_t pid = pids ? (uint32_t)pids[e] : (uint32_t)e;
   const int nq = (d + 3) >> 2;
   float ss = 0.0f;
-  for (int q = tid; q < nq; q += UPD_NT) {
+  for (int q = tid; q < nq; q += AUX_NT) {
     f32x4 zz = {0, 0, 0, 0};
     if (!z) zz = philox_normal4(q, pid, 0u, 2u, seed);
 #pragma unroll
@@ -282,17 +568,17 @@ __global__ __launch_bounds__(UPD_NT) void k_init_momentum(int d, const float *z,
   if ((tid & 63) == 0) red[tid >> 6] = ss;
   __syncthreads();
   float t = 0.0f;
-  for (int w = 0; w < UPD_NT / 64; ++w) t += red[w];
+  for (int w = 0; w < AUX_NT / 64; ++w) t += red[w];
   const float inv = 1.0f / sqrtf(t);
-  for (int i = tid; i < d; i += UPD_NT) u[base + i] *= inv;
+  for (int i = tid; i < d; i += AUX_NT) u[base + i] *= inv;
 }
 
-__global__ __launch_bounds__(UPD_NT) void k_debug_noise(int d, uint64_t seed, const int32_t *pids,
+__global__ __launch_bounds__(AUX_NT) void k_debug_noise(int d, uint64_t seed, const int32_t *pids,
                                                         uint32_t step, uint32_t stage, float *out) {
   const int tid = threadIdx.x, e = blockIdx.x;
   const uint32_t pid = pids ? (uint32_t)pids[e] : (uint32_t)e;
   const int nq = (d + 3) >> 2;
-  for (int q = tid; q < nq; q += UPD_NT) {
+  for (int q = tid; q < nq; q += AUX_NT) {
     const f32x4 zz = philox_normal4(q, pid, step, stage, seed);
     for (int m = 0; m < 4; ++m)
       if (4 * q + m < d) out[(size_t)e * d + 4 * q + m] = zz[m];

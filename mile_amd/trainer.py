@@ -1,0 +1,130 @@
+"""BDETrainer: the caller of the hot path (mirror of src/training/trainer.py:60-177,543-607).
+
+In scope: directory / logging setup, data loading, the probabilistic model, ``train_plan``
+chain grouping and ``start_sampling``.  Out of scope this round: the optax
+warm-start training loop -- chains start from ``warmstart_exp_dir`` params if given, else from
+the prior's initialiser (what the reference does when warm-start is disabled, trainer.py:569-573).
+"""
+from __future__ import annotations
+
+import logging
+import os
+import time
+from contextlib import contextmanager
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from mile_amd import distributed as mdist
+from mile_amd.callbacks import load_params_batch, save_params, save_tree
+from mile_amd.config import Config
+from mile_amd.dataset import TabularLoader
+from mile_amd.probabilistic import ProbabilisticModel
+from mile_amd.sampling import inference_loop
+from mile_amd.spec import ModelSpec
+from mile_amd.tree import PRNGKey
+
+logger = logging.getLogger(__name__)
+
+
+@contextmanager
+def measure_time(name: str):
+    """src/utils.py:25-31: the report notebook greps '<name> took X seconds' from training.log."""
+    t0 = time.time()
+    yield
+    logger.info(f'{name} took {time.time() - t0:.2f} seconds')
+
+
+def train_plan(n_chains: int, n_devices: int) -> list[np.ndarray]:
+    """trainer.py:75-82: array_split(arange(n_chains), n_chains / n_devices); groups run sequentially."""
+    if n_chains % n_devices:
+        raise ValueError('n_chains must be divisible by the number of devices.'
+                         f'{n_chains} % {n_devices} != 0.')
+    return np.array_split(np.arange(n_chains), n_chains // n_devices)
+
+
+class BDETrainer:
+    def __init__(self, config: Config, chains_per_group: int | None = None):
+        assert isinstance(config, Config)
+        self.rank, self.world_size, self.local_rank = mdist.world()
+        self.config = config.setup_dir() if self.rank == 0 else config
+        self._key = PRNGKey(config.rng)
+        self.n_chains = config.n_chains
+        # all chains of a rank advance together in one ensemble launch; `chains_per_group`
+        # reproduces the reference's sequential chain groups when set
+        self.n_devices = chains_per_group or self.n_chains
+        self.train_plan = train_plan(self.n_chains, self.n_devices)
+        if config.data.data_type != 'tabular':
+            raise NotImplementedError('only tabular data is on the MI355X hot path')
+        self.loader = TabularLoader(config.data, rng=config.rng, target_len=config.data.target_len)
+        F = self.loader.train_x.shape[-1]
+        self.spec_model = ModelSpec(in_features=F, hidden_structure=tuple(config.model.hidden_structure),
+                                    activation=config.model.activation,
+                                    task='regr' if config.data.task == 'regr' else 'classification')
+        self.prob_model = ProbabilisticModel(module=self.spec_model, prior=config.training.sampler.prior,
+                                             task=config.data.task, n_batches=1)
+        self.exp_dir = self.config.experiment_dir
+        if self.rank == 0:
+            save_tree(self.exp_dir, self.prob_model.spec)
+        logger.info(f'> Trainer has been successfully initialized\n{self.prob_model}')
+
+    @property
+    def key(self) -> PRNGKey:
+        self._key, k = self._key.split(2)
+        return k
+
+    def init_module_params(self, chain_ids) -> np.ndarray:
+        """Random ParamTree from the prior's initialiser, one stream per GLOBAL chain id."""
+        spec = self.prob_model.spec
+        prior = self.config.training.sampler.prior
+        rows = []
+        for cid in chain_ids:
+            g = torch.Generator().manual_seed((self.config.rng * 1000003 + int(cid)) & 0x7FFFFFFFFFFFFFFF)
+            rows.append(prior.f_init(g, (spec.n_params,)).numpy())
+        return np.stack(rows).astype(np.float32)
+
+    def train_bde(self):
+        with measure_time('time.warmstart'):
+            self.train_warmstart()
+        self.start_sampling()
+
+    def train_warmstart(self):
+        ws = self.config.training.warmstart
+        if ws.include and not ws.warmstart_exp_dir:
+            logger.warning('\t| warm-start training (optax deep ensemble) is outside the MI355X hot path: '
+                           'chains start from the prior initialiser; set warmstart_exp_dir to reuse trained members.')
+        wdir = self.exp_dir / ws._dir_name
+        if self.rank == 0 and not ws.warmstart_exp_dir:
+            params = self.init_module_params(range(self.n_chains))
+            for i in range(self.n_chains):
+                save_params(wdir, self.prob_model.spec, params[i], i)
+
+    def start_sampling(self):
+        """trainer.py:543-607 (full-batch, non-partition branch)."""
+        with measure_time('time.sampling'):
+            cfgs = self.config.training.sampler
+            ws = self.config.training.warmstart
+            warm_exp = ws.warmstart_exp_dir or str(self.exp_dir)
+            warm_path = Path(warm_exp) / ws._dir_name
+            chains = []
+            if warm_path.exists():
+                chains = sorted((warm_path / i for i in os.listdir(warm_path) if i.startswith('params')),
+                                key=lambda p: int(p.stem.split('_')[-1]))
+            x = torch.from_numpy(np.ascontiguousarray(self.loader.train_x))
+            y = torch.from_numpy(np.ascontiguousarray(self.loader.train_y))
+            log_post = self.prob_model.bind(x, y)
+            for step in self.train_plan:
+                mine = mdist.shard_chains(step, self.world_size, self.rank)
+                if len(mine) == 0:
+                    continue
+                logger.info(f'\t| Starting Sampling for chains {mine}')
+                if chains:
+                    params = load_params_batch([chains[i] for i in mine], self.prob_model.spec)
+                else:
+                    logger.warning('\t| No warmstart path found, starting sampling from random params.')
+                    params = self.init_module_params(mine)
+                inference_loop(unnorm_log_posterior=log_post, config=cfgs, rng_key=self.key,
+                               init_params=torch.from_numpy(params), step_ids=mine,
+                               saving_path=self.exp_dir / cfgs._dir_name,
+                               saving_path_warmup=self.exp_dir / cfgs._warmup_dir_name)

@@ -1,0 +1,289 @@
+"""GPU tests of the path around the kernels: golden vectors through the C ABI, sharding
+independence, the tuner, inference_loop's files, the CLI and the LPPD gate (-m gpu)."""
+import math
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+ROOT = Path(__file__).resolve().parents[1]
+GOLD = Path(__file__).parent / 'golden'
+
+
+def _spec(ospec):
+    from mile_amd import ModelSpec
+    return ModelSpec(in_features=ospec.in_features, hidden_structure=ospec.hidden_structure,
+                     activation=ospec.activation, task=ospec.task, prior=ospec.prior,
+                     prior_loc=ospec.prior_loc, prior_scale=ospec.prior_scale)
+
+
+def _engine(ospec, X, y, kernel='auto'):
+    from mile_amd.engine import Engine
+    return Engine(_spec(ospec), torch.from_numpy(np.asarray(X)), torch.from_numpy(np.asarray(y)), device='cuda:0',
+                  grad_kernel=kernel)
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize('name,hs,F,kw,refresh,kernels', [
+    ('regr_relu_8x8', (8, 8, 2), 5, {}, 'O-step-O', ('generic',)),
+    ('regr_relu_8x8_stepO', (8, 8, 2), 5, {}, 'step-O', ('generic',)),
+    ('class_tanh_6x4', (6, 4), 7, dict(activation='tanh', task='classification', prior='Laplace', prior_scale=0.5),
+     'O-step-O', ('generic',)),
+    ('regr_relu_64x3', (64, 64, 64, 2), 5, {}, 'O-step-O', ('generic', 'mfma_w64')),
+])
+def test_hip_reproduces_golden_vectors(oracle, name, hs, F, kw, refresh, kernels):
+    z = np.load(GOLD / f'{name}.npz')
+    ospec = oracle.ModelSpec(F, hs, **kw)
+    T = z['noise'].shape[0]
+    for k in kernels:
+        eng = _engine(ospec, z['X'], z['y'], k)
+        s0 = eng.init(torch.from_numpy(z['theta0']), noise=torch.from_numpy(z['z0']))
+        assert _rel(s0.logdensity.cpu(), z['logp0']) < 1e-5 and _rel(s0.logdensity_grad.cpu(), z['grad0']) < 2e-5
+        assert np.abs(s0.momentum.cpu().numpy() - z['u0']).max() < 1e-6
+        s1, info, _ = eng.step(s0, torch.from_numpy(z['eps']), torch.from_numpy(z['L']), n_steps=1,
+                               noise=torch.from_numpy(z['noise'][:1]), refresh=refresh)
+        assert _rel(s1.position.cpu(), z['x_1']) < 1e-5 and np.abs(s1.momentum.cpu().numpy() - z['u_1']).max() < 2e-5
+        sT, info, _ = eng.step(s0, torch.from_numpy(z['eps']), torch.from_numpy(z['L']), n_steps=T,
+                               noise=torch.from_numpy(z['noise']), refresh=refresh)
+        # fp32 vs the fp64 golden trajectory: 1e-4 after <= 10 steps
+        assert _rel(sT.position.cpu(), z[f'x_{T}']) < 1e-4
+        assert np.abs(sT.momentum.cpu().numpy() - z[f'u_{T}']).max() < 1e-3 * np.abs(z[f'u_{T}']).max()
+        assert _rel(sT.logdensity.cpu(), z[f'logp_{T}']) < 1e-4
+        got = torch.stack([info.logdensity, info.kinetic_change, info.energy_change], -1).cpu().numpy()
+        assert np.abs(got[..., 0] - z['info'][..., 0]).max() < 1e-4 * np.abs(z['info'][..., 0]).max()
+        assert np.abs(got[..., 1] - z['info'][..., 1]).max() < 2e-3 + 1e-3 * np.abs(z['info'][..., 1]).max()
+        assert np.abs(got[..., 2] - z['info'][..., 2]).max() < 2e-2
+
+
+def test_results_do_not_depend_on_sharding(oracle):
+    """Counter RNG keyed by GLOBAL particle id: 8 particles in one ensemble == two shards of 4, bit for bit."""
+    ospec = oracle.ModelSpec(5, (64, 64, 64, 2))
+    prob = oracle.synthetic_problem(ospec, 200, 8, seed=7)
+    eng = _engine(ospec, prob['X'], prob['y'])
+    th, eps, L = (torch.from_numpy(prob[k]) for k in ('theta0', 'eps', 'L'))
+    ids = torch.arange(100, 108, dtype=torch.int32)
+
+    def run(sl):
+        s = eng.init(th[sl], seed=99, particle_ids=ids[sl])
+        s, info, kept = eng.step(s, eps[sl], L[sl], n_steps=7, seed=99, step_offset=3, n_thinning=2, particle_ids=ids[sl])
+        return s, info, kept
+    full, inf_f, kept_f = run(slice(0, 8))
+    a, inf_a, kept_a = run(slice(0, 4))
+    b, inf_b, kept_b = run(slice(4, 8))
+    assert torch.equal(full.position, torch.cat([a.position, b.position]))
+    assert torch.equal(full.momentum, torch.cat([a.momentum, b.momentum]))
+    assert torch.equal(kept_f, torch.cat([kept_a, kept_b], dim=1))
+    assert kept_f.shape[0] == 3                      # global steps 3..9: kept 4, 6, 8
+    assert torch.equal(inf_f.energy_change, torch.cat([inf_a.energy_change, inf_b.energy_change], dim=1))
+    # and a different seed gives a different trajectory
+    s2 = eng.init(th[:4], seed=100, particle_ids=ids[:4])
+    assert not torch.equal(s2.momentum, eng.init(th[:4], seed=99, particle_ids=ids[:4]).momentum)
+
+
+@pytest.mark.parametrize('F,hs', [(5, (7, 6, 2)), (4, (8, 6, 2)), (5, (64, 64, 64, 2))])   # d odd / d % 4 == 0 / d % 4 == 2
+def test_preconditioned_steps_and_alignment_paths(oracle, F, hs):
+    ospec = oracle.ModelSpec(F, hs)
+    d = ospec.n_params
+    E, T = 3, 4
+    prob = oracle.synthetic_problem(ospec, 50, E, seed=13)
+    rng = np.random.default_rng(1)
+    sdc = (0.5 + rng.random((E, d))).astype(np.float32)
+    z0 = rng.standard_normal((E, d)).astype(np.float32)
+    noise = rng.standard_normal((T, 2, E, d)).astype(np.float32)
+    f = lambda th: oracle.logpost_and_grad(ospec, th, prob['X'], prob['y'])
+    st = oracle.mclmc_init(f, prob['theta0'].astype(np.float64), z0.astype(np.float64))
+    for i in range(T):
+        st, _ = oracle.mclmc_step(f, st, prob['eps'].astype(np.float64), prob['L'].astype(np.float64),
+                                  noise[i, 0].astype(np.float64), noise[i, 1].astype(np.float64),
+                                  sqrt_diag_cov=sdc.astype(np.float64))
+    eng = _engine(ospec, prob['X'], prob['y'])
+    s = eng.init(torch.from_numpy(prob['theta0']), noise=torch.from_numpy(z0))
+    s, _, _ = eng.step(s, torch.from_numpy(prob['eps']), torch.from_numpy(prob['L']), n_steps=T,
+                       noise=torch.from_numpy(noise), sqrt_diag_cov=torch.from_numpy(sdc))
+    assert _rel(s.position.cpu(), st.position) < 1e-4
+    assert np.abs(s.momentum.cpu().numpy() - st.momentum).max() < 1e-4
+
+
+def test_kernel_registry_factory_has_blackjax_shape(oracle):
+    from mile_amd.kernels import KERNELS
+    from mile_amd.probabilistic import ProbabilisticModel
+    from mile_amd.tree import PRNGKey, unravel_tree
+    ospec = oracle.ModelSpec(5, (16, 16, 2))
+    prob = oracle.synthetic_problem(ospec, 120, 3, seed=3)
+    pm = ProbabilisticModel(_spec(ospec), task='regr')
+    x, y = torch.from_numpy(prob['X']), torch.from_numpy(prob['y'])
+    log_post = pm.bind(x, y)
+    sampler = KERNELS['mclmc'](log_post, L=torch.from_numpy(prob['L']), step_size=torch.from_numpy(prob['eps']))
+    tree = unravel_tree(pm.spec, torch.from_numpy(prob['theta0']))          # the reference passes a param tree
+    key = PRNGKey(5)
+    state = sampler.init(tree, key)
+    new, info = sampler.step(key, state)
+    # same step on the oracle with the noise the device drew
+    ids = np.arange(3)
+    f = lambda th: oracle.logpost_and_grad(ospec, th, prob['X'], prob['y'])
+    zi = oracle.philox_normal(key.seed, ids, 0, 2, ospec.n_params)
+    st = oracle.mclmc_init(f, prob['theta0'].astype(np.float64), zi)
+    st, oinfo = oracle.mclmc_step(f, st, prob['eps'].astype(np.float64), prob['L'].astype(np.float64),
+                                  oracle.philox_normal(key.seed, ids, 0, 0, ospec.n_params),
+                                  oracle.philox_normal(key.seed, ids, 0, 1, ospec.n_params))
+    assert _rel(new.position.cpu(), st.position) < 1e-5
+    assert _rel(info.logdensity.cpu(), oinfo.logdensity) < 1e-5
+    assert info.energy_change.shape == (3,)
+    assert torch.equal(state.position.cpu(), torch.from_numpy(prob['theta0']))   # step did not mutate its input
+    lp = pm.log_unnormalized_posterior(tree, x, y)
+    assert _rel(lp.cpu(), oracle.logpost_and_grad(ospec, prob['theta0'].astype(np.float64), prob['X'], prob['y'])[0]) < 1e-5
+
+
+def test_warmup_tuner_matches_oracle_with_explicit_noise(oracle):
+    from mile_amd.warmup import mclmc_find_L_and_step_size
+    ospec = oracle.ModelSpec(5, (8, 8, 2))
+    E, d = 3, ospec.n_params
+    prob = oracle.synthetic_problem(ospec, 60, E, seed=21)
+    rng = np.random.default_rng(2)
+    # short horizon: the adaptation amplifies fp32 rounding of the energy error (the oracle run in
+    # fp32 drifts 5-40 % from its own fp64 run after 50 adaptive steps, < 0.5 % after 10)
+    t1, t2, t3 = 8, 3, 4
+    z0 = rng.standard_normal((E, d)).astype(np.float32)
+    noise12 = rng.standard_normal((t1 + t2, 2, E, d)).astype(np.float32)
+    noise3 = rng.standard_normal((t3, 2, E, d)).astype(np.float32)
+    f = lambda th: oracle.logpost_and_grad(ospec, th, prob['X'], prob['y'])
+    kw = dict(step_size_init=0.01, desired_energy_var_start=0.5, desired_energy_var_end=0.1, trust_in_estimate=1.5,
+              num_effective_samples=100)
+    st = oracle.mclmc_init(f, prob['theta0'].astype(np.float64), z0.astype(np.float64))
+    res = oracle.tune_phase12(f, st, lambda i: (noise12[i, 0].astype(np.float64), noise12[i, 1].astype(np.float64)),
+                              t1, t2, record=True, **kw)
+    st3, L3 = oracle.tune_phase3(f, res.state, res.step_size, res.L,
+                                 lambda i: (noise3[i, 0].astype(np.float64), noise3[i, 1].astype(np.float64)), t3)
+    eng = _engine(ospec, prob['X'], prob['y'])
+    s0 = eng.init(torch.from_numpy(prob['theta0']), noise=torch.from_numpy(z0))
+    n12, n3 = torch.from_numpy(noise12).cuda(), torch.from_numpy(noise3).cuda()
+    state, params = mclmc_find_L_and_step_size(
+        eng, s0, 0, tune1_steps=t1, tune2_steps=t2, tune3_steps=t3, diagonal_preconditioning=False,
+        noise_fn=lambda i: n12[i] if i < 10 ** 9 else n3[i - 10 ** 9], **kw)
+    assert _rel(params.step_size.cpu(), res.step_size) < 2e-2
+    assert _rel(params.L.cpu(), L3) < 5e-2
+    assert _rel(state.position.cpu(), st3.position) < 2e-2
+    assert params.sqrt_diag_cov.shape == (E, d) and torch.all(params.sqrt_diag_cov == 1)
+
+
+def test_inference_loop_writes_reference_layout(oracle, tmp_path):
+    from mile_amd.callbacks import load_samples_from_dir
+    from mile_amd.config import SamplerConfig
+    from mile_amd.probabilistic import ProbabilisticModel
+    from mile_amd.sampling import inference_loop, kept_indices
+    from mile_amd.tree import PRNGKey
+    ospec = oracle.ModelSpec(5, (16, 16, 2))
+    prob = oracle.synthetic_problem(ospec, 150, 4, seed=8)
+    pm = ProbabilisticModel(_spec(ospec), task='regr')
+    cfg = SamplerConfig(name='mclmc', warmup_steps=60, n_chains=4, n_samples=45, n_thinning=10,
+                        desired_energy_var_start=0.5, desired_energy_var_end=0.1, step_size_init=0.001)
+    step_ids = np.array([4, 5, 6, 7])
+    kept = inference_loop(pm.bind(torch.from_numpy(prob['X']), torch.from_numpy(prob['y'])), cfg, PRNGKey(4),
+                          torch.from_numpy(prob['theta0']), step_ids, tmp_path / 'samples', return_samples=True,
+                          chunk_steps=20)
+    idx = kept_indices(45, 10).tolist()
+    assert idx == [0, 10, 20, 30, 40]
+    for c in step_ids:                                              # integer file naming is exact
+        assert sorted(p.name for p in (tmp_path / 'samples' / str(c)).iterdir()) == sorted(f'sample_{n}.npz' for n in idx)
+    assert (tmp_path / 'samples' / 'info.pkl').exists()
+    lines = (tmp_path / 'warmup_params.txt').read_text().strip().split('\n')
+    assert len(lines) == 2 and all(len(l.split(',')) == 4 for l in lines)
+    eps = np.array([float(v) for v in lines[0].split(',')])
+    assert np.all(eps > 0) and np.all(np.isfinite(eps))
+    back = load_samples_from_dir(tmp_path / 'samples', pm.spec)     # [chains, saved, d]
+    assert back.shape == (4, 5, ospec.n_params)
+    assert np.array_equal(back, kept.permute(1, 0, 2).numpy())      # files hold exactly the kept positions
+    assert np.isfinite(back).all()
+
+
+def test_train_cli_runs_the_yaml_surface(tmp_path):
+    import yaml
+    cfg = yaml.safe_load((ROOT / 'experiments' / 'smoke_synthetic.yaml').read_text())
+    cfg['saving_dir'] = str(tmp_path)
+    cfg['training']['sampler'].update(warmup_steps=50, n_samples=30, n_chains=4)
+    (tmp_path / 'cfg.yaml').write_text(yaml.safe_dump(cfg))
+    r = subprocess.run([sys.executable, str(ROOT / 'train.py'), '-c', str(tmp_path / 'cfg.yaml'), '-d', '1'],
+                       capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    exp = tmp_path / 'smoke_synthetic'
+    assert (exp / 'config.yaml').exists() and (exp / 'warmup_params.txt').exists() and (exp / 'tree').exists()
+    assert sorted(p.name for p in (exp / 'samples').iterdir() if p.is_dir()) == ['0', '1', '2', '3']
+    assert sorted(p.name for p in (exp / 'samples' / '2').iterdir()) == ['sample_0.npz', 'sample_10.npz', 'sample_20.npz']
+    log = (exp / 'training.log').read_text()
+    assert 'time.sampling took' in log and 'Starting mclmc Sampling' in log
+
+
+def test_lppd_matches_oracle_after_equal_step_count(oracle):
+    """The +-1 % LPPD gate of BASELINE.json on a short equal-noise run."""
+    from mile_amd.metrics import lppd, pointwise_lppd, predict
+    ospec = oracle.ModelSpec(5, (16, 16, 2))
+    E, T, N = 4, 60, 200
+    prob = oracle.synthetic_problem(ospec, N, E, seed=31)
+    rng = np.random.default_rng(9)
+    d = ospec.n_params
+    z0 = rng.standard_normal((E, d)).astype(np.float32)
+    noise = rng.standard_normal((T, 2, E, d)).astype(np.float32)
+    Xt = rng.standard_normal((77, 5)).astype(np.float32)
+    yt = rng.standard_normal(77).astype(np.float32)
+    f = lambda th: oracle.logpost_and_grad(ospec, th, prob['X'], prob['y'])
+    st = oracle.mclmc_init(f, prob['theta0'].astype(np.float64), z0.astype(np.float64))
+    st, okept, oidx = oracle.sample_chain(f, st, prob['eps'].astype(np.float64) * 3, prob['L'].astype(np.float64),
+                                          lambda i: (noise[i, 0].astype(np.float64), noise[i, 1].astype(np.float64)), T, 5)
+    assert oidx.tolist() == list(range(0, T, 5))
+    o_out = oracle.mlp_forward(ospec, okept.reshape(-1, d), Xt).reshape(len(oidx), E, 77, 2).transpose(1, 0, 2, 3)
+    o_lppd = oracle.lppd(oracle.pointwise_lppd(ospec, o_out, yt))
+    eng = _engine(ospec, prob['X'], prob['y'])
+    s = eng.init(torch.from_numpy(prob['theta0']), noise=torch.from_numpy(z0))
+    s, _, kept = eng.step(s, torch.from_numpy(prob['eps']) * 3, torch.from_numpy(prob['L']), n_steps=T,
+                          noise=torch.from_numpy(noise), n_thinning=5)
+    out = predict(_spec(ospec), kept.permute(1, 0, 2), torch.from_numpy(Xt).cuda())       # [C, S, N, 2]
+    got = lppd(pointwise_lppd(out, torch.from_numpy(yt), 'regr')).item()
+    assert abs(got - o_lppd) < 0.01 * abs(o_lppd), (got, o_lppd)
+
+
+def test_full_size_properties_b2(oracle):
+    """Size-independent properties at BASELINE's full B2 size (N=1052, E=128, d=8834)."""
+    ospec, N, E = oracle.config_spec('B2')
+    prob = oracle.synthetic_problem(ospec, N, E, seed=0)
+    th = torch.from_numpy(prob['theta0'])
+    mf = _engine(ospec, prob['X'], prob['y'], 'mfma_w64')
+    ge = _engine(ospec, prob['X'], prob['y'], 'generic')
+    lp1, g1 = mf.logpost_grad(th)
+    lp2, g2 = ge.logpost_grad(th)
+    # two independent HIP implementations agree
+    assert _rel(lp1.cpu(), lp2.cpu()) < 2e-6 and _rel(g1.cpu(), g2.cpu()) < 2e-5
+    # a subset against the fp64 oracle
+    lo, go = oracle.logpost_and_grad(ospec, prob['theta0'][:6].astype(np.float64), prob['X'], prob['y'])
+    assert _rel(lp1[:6].cpu(), lo) < 2e-6 and _rel(g1[:6].cpu(), go) < 2e-5
+    # additivity over data: likelihood gradient of all rows == sum over two halves (the prior counted once)
+    h = 500
+    a = _engine(ospec, prob['X'][:h], prob['y'][:h], 'mfma_w64').logpost_grad(th)
+    b = _engine(ospec, prob['X'][h:], prob['y'][h:], 'mfma_w64').logpost_grad(th)
+    prior_g = -th.cuda()
+    assert _rel((a[1] + b[1] - prior_g).cpu(), g1.cpu()) < 2e-5
+    prior_v = (-0.5 * th.double() ** 2).sum(1) - ospec.n_params * 0.5 * math.log(2 * math.pi)
+    assert _rel((a[0].cpu().double() + b[0].cpu().double() - prior_v), lp1.cpu()) < 2e-6
+    # steps: unit momentum, determinism, finite energy bookkeeping
+    ids = torch.arange(E, dtype=torch.int32)
+    s0 = mf.init(th, seed=5, particle_ids=ids)
+    s1, info, kept = mf.step(s0, torch.from_numpy(prob['eps']), torch.from_numpy(prob['L']), n_steps=20, seed=5,
+                             n_thinning=10, particle_ids=ids)
+    s1b, info_b, _ = mf.step(s0, torch.from_numpy(prob['eps']), torch.from_numpy(prob['L']), n_steps=20, seed=5,
+                             n_thinning=10, particle_ids=ids)
+    assert torch.equal(s1.position, s1b.position) and torch.equal(info.energy_change, info_b.energy_change)
+    assert (s1.momentum.double().norm(dim=1) - 1).abs().max().item() < 1e-5
+    assert kept.shape == (2, E, ospec.n_params) and torch.isfinite(kept).all()
+    assert torch.isfinite(info.energy_change).all()
+    # energy_change = kinetic_change - l_new + l_old, consistently
+    l_prev = torch.cat([s0.logdensity[None], info.logdensity[:-1]])
+    assert (info.energy_change - (info.kinetic_change - info.logdensity + l_prev)).abs().max().item() < 5e-2

@@ -1,0 +1,318 @@
+"""CPU tests of the host side: C-ABI surface, layouts, config, I/O formats, tuner arithmetic,
+diagnostics, LPPD and the world_size-2 (gloo) sharding path.  No GPU compute."""
+import math
+import os
+import re
+import sys
+from functools import partial
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mclmc_oracle as O
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+# ---------------------------------------------------------------- C ABI -----------------
+def test_library_exports_every_declared_symbol():
+    from mile_amd import _lib
+    from mile_amd._build import build_library
+    build_library()                                   # hipcc cross-compiles without a GPU
+    lib = _lib.load_library()
+    header = (ROOT / 'include' / 'mile_hip.h').read_text()
+    declared = set(re.findall(r'\b(mile_[a-z_]+)\s*\(', header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.mile_abi_version() == _lib.ABI_VERSION
+    # struct layouts agree with the header's field order
+    assert [f[0] for f in _lib.StepArgsC._fields_] == re.findall(r'^\s+(?:const\s+)?\w+\s*\*?\s*(\w+);', re.search(
+        r'typedef struct mile_step_args \{(.*?)\} mile_step_args;', header, re.S).group(1), re.M)
+
+
+def test_host_calls_that_need_no_gpu():
+    """create / param_count / param_offsets / destroy and argument validation run on the host."""
+    import ctypes as C
+    from mile_amd import _lib
+    lib = _lib.load_library()
+    cs = _lib.ModelSpecC()
+    cs.in_features, cs.n_layers = 5, 12
+    for i in range(12):
+        cs.widths[i] = 4
+    cs.widths[11] = 2
+    cs.activation, cs.task, cs.prior, cs.prior_loc, cs.prior_scale, cs.use_bias = 0, 0, 0, 0.0, 1.0, 1
+    h = C.c_void_p()
+    assert lib.mile_create(C.byref(cs), 0, C.byref(h)) == 0
+    spec = O.ModelSpec(5, (4,) * 11 + (2,))
+    assert lib.mile_param_count(h) == spec.n_params
+    for li, ent in enumerate(O.param_slices(spec)):      # same ravel order incl. layer10 < layer2
+        b, k = C.c_int64(), C.c_int64()
+        assert lib.mile_param_offsets(h, li, C.byref(b), C.byref(k)) == 0
+        assert (b.value, k.value) == (ent['bias'][0], ent['kernel'][0])
+    assert lib.mile_destroy(h) == 0
+    cs.widths[11] = 3                                     # regression needs width 2
+    assert lib.mile_create(C.byref(cs), 0, C.byref(h)) == -1
+    assert b'width 2' in lib.mile_last_error()
+    cs.widths[11] = 2
+    cs.prior_scale = 0.0
+    assert lib.mile_create(C.byref(cs), 0, C.byref(h)) == -1
+
+
+def test_product_path_fails_loudly_without_gpu_or_library(tmp_path):
+    from mile_amd import ModelSpec, _lib
+    with pytest.raises(_lib.MileHipError):
+        _lib.load_library(tmp_path / 'nope.so')
+    if not torch.cuda.is_available():
+        from mile_amd.engine import Engine
+        with pytest.raises(_lib.MileHipError):
+            Engine(ModelSpec(5, (8, 2)), torch.zeros(4, 5), torch.zeros(4))
+
+
+def test_product_never_imports_the_oracle():
+    for p in (ROOT / 'mile_amd').rglob('*.py'):
+        assert 'oracle' not in re.sub(r'#.*', '', p.read_text()).replace('"""', ''), p
+    assert 'oracle' not in (ROOT / 'train.py').read_text()
+
+
+# ---------------------------------------------------------------- layout / tree ----------
+def test_spec_leaves_and_tree_roundtrip():
+    from mile_amd import ModelSpec
+    from mile_amd.tree import get_flattened_keys, ravel_tree, unravel_tree
+    spec = ModelSpec(5, (16, 16, 2))
+    ospec = O.ModelSpec(5, (16, 16, 2))
+    assert [n for n, _, _ in spec.leaves()] == O.flattened_keys(ospec)
+    assert spec.n_params == ospec.n_params == 402
+    flat = torch.arange(3 * 402, dtype=torch.float32).reshape(3, 402)
+    tree = unravel_tree(spec, flat)
+    assert get_flattened_keys(tree) == O.flattened_keys(ospec)
+    assert tree['fcn']['layer0']['kernel'].shape == (3, 5, 16)
+    assert torch.equal(ravel_tree(spec, tree), flat)
+    # same slices as the oracle's unravel
+    (W0, b0), *_ = O.unravel(ospec, flat.numpy())
+    assert np.array_equal(tree['fcn']['layer0']['kernel'].numpy(), W0) and np.array_equal(tree['fcn']['layer0']['bias'].numpy(), b0)
+    big = ModelSpec(3, (4,) * 11 + (2,))
+    assert [n for n, _, _ in big.leaves()] == O.flattened_keys(O.ModelSpec(3, (4,) * 11 + (2,)))
+
+
+def test_prng_key_split_is_deterministic_and_distinct():
+    from mile_amd.tree import PRNGKey
+    k = PRNGKey(4)
+    a, b, c = k.split(3)
+    assert (a.seed, b.seed, c.seed) == tuple(x.seed for x in PRNGKey(4).split(3))
+    assert len({a.seed, b.seed, c.seed, k.seed}) == 4
+    assert k.fold_in(1).seed != k.fold_in(2).seed
+
+
+# ---------------------------------------------------------------- config ----------------
+def test_config_accepts_reference_schema_and_rejects_unknown_keys(tmp_path):
+    import yaml
+    from mile_amd.config import Config, ConfigError
+    cfg = Config.from_file(ROOT / 'experiments' / 'mclmc_airfoil_b1.yaml')
+    s = cfg.training.sampler
+    assert (s.name, s.warmup_steps, s.n_chains, s.n_samples, s.n_thinning) == ('mclmc', 50000, 16, 10000, 10)
+    assert cfg.model.hidden_structure == [64, 64, 64, 2] and s.prior.name == 'StandardNormal'
+    assert (s.desired_energy_var_start, s.desired_energy_var_end, s.step_size_init) == (0.5, 0.1, 0.001)
+    d = cfg.to_dict()
+    d['training']['sampler']['not_a_field'] = 1
+    (tmp_path / 'bad.yaml').write_text(yaml.safe_dump(d))
+    with pytest.raises(ConfigError, match='unknown field'):
+        Config.from_file(tmp_path / 'bad.yaml')
+    d = cfg.to_dict()
+    del d['data']['path']
+    with pytest.raises(ConfigError, match='missing required'):
+        Config.from_dict(d)
+    ref = Path('/root/reference/experiments/replicate_uci/mclmc.yaml')
+    if ref.exists():                                    # the reference's own YAML parses unchanged
+        r = Config.from_file(ref)
+        assert r.n_chains == 12 and r.model.hidden_structure == [16, 16, 2]
+    from mile_amd.kernels import KERNELS, WARMUP_KERNELS
+    assert s.kernel is KERNELS['mclmc'] and WARMUP_KERNELS == {}
+
+
+def test_train_plan_matches_reference_semantics():
+    from mile_amd.sampling import kept_indices
+    from mile_amd.trainer import train_plan
+    assert [p.tolist() for p in train_plan(12, 4)] == [p.tolist() for p in O.train_plan(12, 4)]
+    with pytest.raises(ValueError):
+        train_plan(12, 5)
+    for n, t in ((10000, 10), (25, 10), (7, 1), (5, 100)):
+        assert np.array_equal(kept_indices(n, t), O.kept_indices(n, t))
+        assert kept_indices(n, t).dtype == np.int32
+
+
+# ---------------------------------------------------------------- I/O -------------------
+def test_sample_files_have_reference_layout(tmp_path):
+    from mile_amd import ModelSpec
+    from mile_amd.callbacks import (load_params_batch, load_samples_from_dir, save_flat_sample, save_params,
+                                    save_position)
+    from mile_amd.tree import unravel_tree
+    spec = ModelSpec(5, (16, 16, 2))
+    rng = np.random.default_rng(0)
+    flat = rng.standard_normal((2, 3, 402)).astype(np.float32)        # [chains, samples, d]
+    for c in range(2):
+        for k, n in enumerate((0, 10, 20)):
+            save_flat_sample(spec, flat[c, k], tmp_path / 'samples', idx=c + 4, n=n)
+    f = tmp_path / 'samples' / '4' / 'sample_10.npz'
+    assert f.exists()
+    with np.load(f) as z:
+        assert z.files == ['fcn.layer0.bias', 'fcn.layer0.kernel', 'fcn.layer1.bias', 'fcn.layer1.kernel',
+                           'fcn.layer2.bias', 'fcn.layer2.kernel']
+        assert z['fcn.layer0.kernel'].shape == (5, 16) and z['fcn.layer0.kernel'].dtype == np.float32
+    back = load_samples_from_dir(tmp_path / 'samples', spec)
+    assert back.shape == (2, 3, 402) and np.array_equal(back, flat)
+    # save_position on a tree writes the identical file
+    tree = unravel_tree(spec, torch.from_numpy(flat[0, 1]))
+    save_position(tree, tmp_path / 's2', idx=np.int32(4), n=10)
+    with np.load(tmp_path / 's2' / '4' / 'sample_10.npz') as z2, np.load(f) as z:
+        assert z2.files == z.files and all(np.array_equal(z2[k], z[k]) for k in z.files)
+    # warm-start params: sorted by integer suffix, not lexicographically
+    for i in (0, 2, 10):
+        save_params(tmp_path / 'warmstart', spec, flat[0, 0] + i, i)
+    files = [tmp_path / 'warmstart' / f'params_{i}.npz' for i in (10, 2, 0)]
+    got = load_params_batch(files, spec)
+    assert np.allclose(got[:, 0] - flat[0, 0, 0], [0, 2, 10])
+    assert (tmp_path / 'tree').exists()
+
+
+def test_tabular_loader_normalises_and_splits(tmp_path):
+    from mile_amd.config import DataConfig
+    from mile_amd.dataset import TabularLoader
+    rng = np.random.default_rng(1)
+    data = rng.standard_normal((103, 6)) * 5 + 2
+    np.savetxt(tmp_path / 'toy.data', data, delimiter=' ')
+    cfg = DataConfig(path=str(tmp_path / 'toy.data'), source='local', data_type='tabular', task='regr',
+                     normalize=True, train_split=0.7, valid_split=0.1, test_split=0.2)
+    ld = TabularLoader(cfg, rng=4)
+    assert len(ld.data_train) == int(103 * 0.7) and len(ld.data_valid) == int(103 * 0.8) - int(103 * 0.7)
+    assert ld.train_x.shape == (72, 5) and ld.train_y.shape == (72,)
+    assert np.abs(ld.data.mean(axis=0)).max() < 1e-5 and np.abs(ld.data.std(axis=0) - 1).max() < 1e-4
+    syn = TabularLoader(DataConfig(path='200x5', source='synthetic', data_type='tabular', task='regr'), rng=0)
+    assert syn.train_x.shape == (160, 5)
+
+
+# ---------------------------------------------------------------- tuner arithmetic -------
+def test_predictor_update_and_nan_handling_match_oracle_formulas():
+    from mile_amd.engine import IntegratorState
+    from mile_amd.warmup import desired_energy_var, handle_nans, predictor_update, streaming_average_update
+    for step in (0, 7, 101, 400):
+        for start in (0.5, 5.0):
+            assert desired_energy_var(step, 101, start, 0.1) == pytest.approx(O.desired_energy_var(step, 101, start, 0.1), rel=1e-12)
+    E, d = 5, 30
+    rng = np.random.default_rng(2)
+    dE = torch.tensor(rng.standard_normal(E), dtype=torch.float64)
+    eps = torch.full((E,), 0.01, dtype=torch.float64)
+    time, xavg = torch.rand(E, dtype=torch.float64), torch.rand(E, dtype=torch.float64) * 1e10
+    # handle_nans has already turned the initial inf into the largest finite float (nan_to_num),
+    # which is what keeps `(new > max) * max` from being 0 * inf
+    big = float(np.finfo(np.float32).max)
+    emax = torch.tensor([big, 0.005, big, 1e-4, big], dtype=torch.float64)
+    new, t2, x2 = predictor_update(dE, eps, time, xavg, emax, dim=d, desired_var=0.3, trust_in_estimate=1.5,
+                                   decay_rate=99 / 101)
+    xi = dE.numpy() ** 2 / (d * 0.3) + 1e-8
+    w = np.exp(-0.5 * (np.log(xi) / 9.0) ** 2)
+    xr = 99 / 101 * xavg.numpy() + w * xi / 0.01 ** 6
+    tr = 99 / 101 * time.numpy() + w
+    ref = np.minimum((xr / tr) ** (-1 / 6), emax.numpy())
+    assert np.allclose(new.numpy(), ref, rtol=1e-12) and np.allclose(t2.numpy(), tr) and np.allclose(x2.numpy(), xr)
+    # handle_nans: chain 1 diverged
+    prev = IntegratorState(torch.zeros(2, 4), torch.ones(2, 4), torch.zeros(2), torch.ones(2, 4))
+    pos = torch.ones(2, 4)
+    pos[1, 2] = float('nan')
+    nxt = IntegratorState(pos, 2 * torch.ones(2, 4), torch.tensor([1.0, float('nan')]), 3 * torch.ones(2, 4))
+    ok, st, emax2, dE2 = handle_nans(prev, nxt, torch.tensor([0.1, 0.2]), torch.tensor([float('inf')] * 2),
+                                     torch.tensor([0.5, float('nan')]))
+    assert ok.tolist() == [True, False]
+    assert torch.equal(st.position[1], prev.position[1]) and torch.equal(st.position[0], nxt.position[0])
+    assert emax2[1].item() == pytest.approx(0.16) and emax2[0].item() > 1e30 and dE2.tolist() == [0.5, 0.0]
+    o_ok, o_st, o_emax, o_dE = O.handle_nans(
+        O.State(prev.position.numpy(), prev.momentum.numpy(), prev.logdensity.numpy(), prev.logdensity_grad.numpy()),
+        O.State(nxt.position.numpy(), nxt.momentum.numpy(), nxt.logdensity.numpy(), nxt.logdensity_grad.numpy()),
+        np.array([0.1, 0.2], np.float32), np.array([np.inf, np.inf], np.float32), np.array([0.5, np.nan], np.float32))
+    assert o_ok.tolist() == ok.tolist() and np.allclose(o_st.position, st.position.numpy()) and np.allclose(o_dE, dE2.numpy())
+    # streaming average
+    W, avg = torch.zeros(2), torch.zeros(2, 2, 3)
+    val = torch.arange(12, dtype=torch.float32).reshape(2, 2, 3)
+    W1, a1 = streaming_average_update(val, (W, avg), torch.tensor([0.5, 0.0]), torch.tensor([0.0, 1.0]))
+    oW, oa = O.streaming_average_update(val.numpy(), (W.numpy(), avg.numpy()), np.array([0.5, 0.0], np.float32), np.array([0.0, 1.0], np.float32))
+    assert np.allclose(W1.numpy(), oW) and np.allclose(a1.numpy(), oa)
+
+
+def test_effective_sample_size_matches_oracle():
+    from mile_amd.diagnostics import effective_sample_size
+    rng = np.random.default_rng(3)
+    for phi, S, C in ((0.9, 2001, 1), (0.0, 500, 1), (0.97, 1500, 3), (-0.4, 999, 2)):
+        x = np.zeros((C, S, 6))
+        e = rng.standard_normal((C, S, 6))
+        for t in range(1, S):
+            x[:, t] = phi * x[:, t - 1] + e[:, t]
+        got = effective_sample_size(torch.from_numpy(x)).numpy()
+        assert np.allclose(got, O.effective_sample_size(x), rtol=1e-9)
+
+
+def test_lppd_and_predict_match_oracle():
+    from mile_amd import ModelSpec
+    from mile_amd.metrics import lppd, pointwise_lppd, predict, running_lppd
+    for task, hs in (('regr', (8, 8, 2)), ('classification', (8, 5))):
+        ospec = O.ModelSpec(4, hs, activation='tanh', task=task)
+        spec = ModelSpec(4, hs, activation='tanh', task=task)
+        pr = O.synthetic_problem(ospec, 21, 6, seed=5)
+        flat = torch.from_numpy(pr['theta0']).double().reshape(2, 3, -1)          # [C, S, d]
+        out = predict(spec, flat, torch.from_numpy(pr['X']).double())
+        ref = O.mlp_forward(ospec, pr['theta0'].astype(np.float64), pr['X']).reshape(2, 3, 21, -1)
+        assert np.allclose(out.numpy(), ref, atol=1e-10)
+        pw = pointwise_lppd(torch.from_numpy(ref), torch.from_numpy(pr['y']), task)
+        opw = O.pointwise_lppd(ospec, ref, pr['y'])
+        assert np.allclose(pw.numpy(), opw, rtol=1e-10, atol=1e-12)
+        assert lppd(pw).item() == pytest.approx(O.lppd(opw), rel=1e-12)
+        assert running_lppd(pw)[-1].item() == pytest.approx(
+            np.log(np.exp(opw).mean(axis=1)).mean(axis=-1).mean(), rel=1e-10)
+
+
+def test_kernel_factory_rejects_arbitrary_callables():
+    from mile_amd.probabilistic import ProbabilisticModel, resolve_target
+    from mile_amd import ModelSpec
+    with pytest.raises(TypeError, match='ProbabilisticModel'):
+        resolve_target(lambda p: 0.0)
+    pm = ProbabilisticModel(ModelSpec(5, (8, 2)), task='regr')
+    x, y = torch.zeros(4, 5), torch.zeros(4)
+    m, xx, yy = resolve_target(pm.bind(x, y))
+    assert m is pm and xx is x and yy is y
+    m, _, _ = resolve_target(partial(pm.log_unnormalized_posterior, x=x, y=y))
+    assert m is pm and pm.spec.prior == 'StandardNormal' and pm.n_params == 66
+    with pytest.raises(NotImplementedError, match='Mini-Batch'):
+        ProbabilisticModel(ModelSpec(5, (8, 2)), n_batches=2)
+
+
+# ---------------------------------------------------------------- world_size 2 (gloo) ----
+def _dist_worker(rank, ws, port, tmp):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as dist
+    from mile_amd import distributed as md
+    from mile_amd.metrics import lppd
+    dist.init_process_group('gloo', rank=rank, world_size=ws)
+    ids = md.shard_chains(np.arange(6), ws, rank)
+    assert ids.tolist() == ([0, 1, 2] if rank == 0 else [3, 4, 5])
+    g = torch.Generator().manual_seed(0)
+    full = torch.randn(4, 6, 7, generator=g)                       # [K, E, d] the whole ensemble
+    mine = full[:, ids[0]:ids[-1] + 1].contiguous()
+    out, work = md.gather_samples(mine, async_op=True)
+    work.wait()
+    assert torch.equal(out.contiguous(), full)                     # rank-major == chain order
+    pw = torch.randn(6, 5, 9, generator=g)                         # [C, S, N]
+    val = md.lppd_distributed(pw[ids[0]:ids[-1] + 1], total_chains=6)
+    assert abs(val.item() - lppd(pw).item()) < 1e-6
+    torch.save(torch.tensor(1), Path(tmp) / f'ok{rank}')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharding_and_sample_collection_world_size_2(tmp_path):
+    import torch.multiprocessing as mp
+    port = 29600 + os.getpid() % 300
+    mp.spawn(_dist_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / 'ok0').exists() and (tmp_path / 'ok1').exists()

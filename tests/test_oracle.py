@@ -1,0 +1,253 @@
+"""CPU tests of the oracle: known answers, invariants and the committed golden vectors."""
+import math
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import mclmc_oracle as O
+
+GOLD = Path(__file__).parent / 'golden'
+
+
+def test_philox_known_answer_vectors():
+    # Random123 kat_vectors for philox4x32-10
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, exp in kat:
+        got = O.philox4x32(np.array(ctr, np.uint32), np.array(key, np.uint32))
+        assert tuple(int(v) for v in got) == exp
+
+
+def test_philox_normal_moments_and_sharding_independence():
+    ids = np.arange(6)
+    z = O.philox_normal(42, ids, 3, 1, 4001)
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02
+    # a particle's stream depends on its GLOBAL id only
+    z2 = O.philox_normal(42, ids[3:], 3, 1, 4001)
+    assert np.array_equal(z[3:], z2)
+
+
+@pytest.mark.parametrize('act,task,prior', [('relu', 'regr', 'Normal'), ('tanh', 'regr', 'Laplace'),
+                                            ('sigmoid', 'classification', 'Normal'), ('relu', 'classification', 'Laplace')])
+def test_gradient_matches_torch_autograd_fp64(act, task, prior):
+    torch = pytest.importorskip('torch')
+    hs = (9, 6, 2) if task == 'regr' else (9, 6, 4)
+    spec = O.ModelSpec(5, hs, activation=act, task=task, prior=prior, prior_loc=0.1, prior_scale=0.8)
+    pr = O.synthetic_problem(spec, 37, 3, seed=4)
+    th = pr['theta0'].astype(np.float64)
+    lp, g = O.logpost_and_grad(spec, th, pr['X'], pr['y'])
+    t = torch.tensor(th, requires_grad=True)
+    X = torch.tensor(pr['X'], dtype=torch.float64)
+    y = torch.tensor(pr['y'])
+    actf = {'relu': torch.relu, 'tanh': torch.tanh, 'sigmoid': torch.sigmoid}[act]
+    vals = []
+    for e in range(3):
+        h, off, fin = X, 0, 5
+        for li, w in enumerate(hs):
+            b = t[e, off:off + w]; off += w
+            W = t[e, off:off + fin * w].reshape(fin, w); off += fin * w
+            h = h @ W + b
+            if li < len(hs) - 1:
+                h = actf(h)
+            fin = w
+        if task == 'regr':
+            ll = torch.distributions.Normal(h[:, 0], torch.exp(h[:, 1]).clamp(1e-6, 1e6)).log_prob(y.double()).sum()
+        else:
+            ll = torch.distributions.Categorical(logits=h).log_prob(y.long()).sum()
+        loc, sc = torch.tensor(0.1, dtype=torch.float64), torch.tensor(0.8, dtype=torch.float64)
+        pd = torch.distributions.Normal(loc, sc) if prior == 'Normal' else torch.distributions.Laplace(loc, sc)
+        vals.append(ll + pd.log_prob(t[e]).sum())
+    v = torch.stack(vals)
+    v.sum().backward()
+    assert np.abs(v.detach().numpy() - lp).max() < 1e-10
+    assert np.abs(t.grad.numpy() - g).max() < 1e-10
+
+
+def test_param_layout_is_ravel_pytree_order():
+    spec = O.ModelSpec(3, (4,) * 11 + (2,))
+    order = O.layer_order(12)
+    assert order[:4] == [0, 1, 10, 11] and order[4] == 2          # 'layer10' < 'layer2'
+    keys = O.flattened_keys(spec)
+    assert keys[0] == 'fcn.layer0.bias' and keys[1] == 'fcn.layer0.kernel' and keys[4] == 'fcn.layer10.bias'
+    ents = O.param_slices(spec)
+    assert ents[0]['bias'] == (0, 4) and ents[0]['kernel'] == (4, 16)
+    assert ents[10]['bias'][0] == ents[1]['kernel'][1]             # layer10 right after layer1
+    assert sum(e['kernel'][1] - e['kernel'][0] + 4 - (2 if e['layer'] == 11 else 0) for e in ents) == spec.n_params
+
+
+def _rand_unit(rng, E, d):
+    u = rng.standard_normal((E, d))
+    return u / np.linalg.norm(u, axis=1, keepdims=True)
+
+
+def test_b_step_invariants_and_closed_form():
+    rng = np.random.default_rng(0)
+    E, d = 4, 50
+    u, g = _rand_unit(rng, E, d), 30 * rng.standard_normal((E, d))
+    eps = np.full(E, 0.3)
+    un, v, dK = O.esh_momentum_update(u, g, eps, 0.7)
+    assert np.abs(np.linalg.norm(un, axis=1) - 1).max() < 1e-14
+    un0, _, dK0 = O.esh_momentum_update(u, g, np.full(E, 1e-14), 0.7)
+    assert np.abs(un0 - u).max() < 1e-12 and np.abs(dK0).max() < 1e-10      # eps -> 0 is the identity
+    # u orthogonal to e: u' = (e (1 - zeta^2) + 2 zeta u)/(1 + zeta^2), dK = (d-1)(delta - ln2 + ln(1 + zeta^2))
+    e = g / np.linalg.norm(g, axis=1, keepdims=True)
+    uo = u - (u * e).sum(1, keepdims=True) * e
+    uo /= np.linalg.norm(uo, axis=1, keepdims=True)
+    un, _, dK = O.esh_momentum_update(uo, g, eps, 0.7)
+    delta = 0.3 * 0.7 * np.linalg.norm(g, axis=1) / (d - 1)
+    zeta = np.exp(-delta)
+    ref = (e * (1 - zeta**2)[:, None] + 2 * zeta[:, None] * uo) / (1 + zeta**2)[:, None]
+    assert np.abs(un - ref).max() < 1e-13
+    assert np.abs(dK - (d - 1) * (delta - math.log(2) + np.log(1 + zeta**2))).max() < 1e-10
+
+
+def _gauss_target(th):
+    return -0.5 * (th * th).sum(axis=1), -th
+
+
+def test_mclachlan_is_time_reversible():
+    rng = np.random.default_rng(1)
+    E, d = 3, 20
+    x, u = rng.standard_normal((E, d)), _rand_unit(rng, E, d)
+    l, g = _gauss_target(x)
+    st0 = O.State(x, u, l, g)
+    eps = np.full(E, 0.2)
+    st1, dK = O.mclachlan_step(_gauss_target, st0, eps)
+    back, dKb = O.mclachlan_step(_gauss_target, O.State(st1.position, -st1.momentum, st1.logdensity, st1.logdensity_grad), eps)
+    assert np.abs(back.position - x).max() < 1e-12
+    assert np.abs(-back.momentum - u).max() < 1e-12
+    assert np.abs(dK + dKb).max() < 1e-10
+
+
+def test_partial_refresh_limits():
+    rng = np.random.default_rng(2)
+    u, z = _rand_unit(rng, 2, 30), rng.standard_normal((2, 30))
+    out = O.partial_refresh(u, z, np.full(2, 0.01), np.full(2, 1e12))
+    assert np.abs(out - u).max() < 1e-6                         # nu -> 0 as L -> inf
+    out = O.partial_refresh(u, z, np.full(2, 0.5), np.full(2, 3.0))
+    assert np.abs(np.linalg.norm(out, axis=1) - 1).max() < 1e-14
+
+
+def test_energy_error_order_on_gaussian():
+    """isokinetic McLachlan is 2nd order: the one-step energy error scales like eps^3."""
+    rng = np.random.default_rng(3)
+    E, d = 64, 100
+    x, u = rng.standard_normal((E, d)), _rand_unit(rng, E, d)
+    l, g = _gauss_target(x)
+    errs = []
+    for eps in (0.4, 0.2, 0.1):
+        st, dK = O.mclachlan_step(_gauss_target, O.State(x, u, l, g), np.full(E, eps))
+        errs.append(np.sqrt(np.mean((dK - st.logdensity + l) ** 2)))
+    assert 5.0 < errs[0] / errs[1] < 12.0 and 5.0 < errs[1] / errs[2] < 12.0
+
+
+def test_standard_gaussian_stationary_moments():
+    rng = np.random.default_rng(4)
+    E, d, T = 8, 50, 3000
+    st = O.mclmc_init(_gauss_target, rng.standard_normal((E, d)), rng.standard_normal((E, d)))
+    eps, L = np.full(E, 0.5), np.full(E, math.sqrt(d))
+    acc = []
+    for i in range(T):
+        st, info = O.mclmc_step(_gauss_target, st, eps, L, rng.standard_normal((E, d)), rng.standard_normal((E, d)))
+        if i >= 500:
+            acc.append(st.position.copy())
+    xs = np.concatenate(acc)
+    assert abs(xs.mean()) < 0.05 and abs(xs.var() - 1.0) < 0.1
+
+
+def test_refresh_switch_differs_only_in_placement():
+    rng = np.random.default_rng(5)
+    E, d = 2, 10
+    st = O.mclmc_init(_gauss_target, rng.standard_normal((E, d)), rng.standard_normal((E, d)))
+    z1, z2 = rng.standard_normal((E, d)), rng.standard_normal((E, d))
+    a, _ = O.mclmc_step(_gauss_target, st, np.full(E, 0.1), np.full(E, 3.0), z1, z2, refresh='O-step-O')
+    b, _ = O.mclmc_step(_gauss_target, st, np.full(E, 0.1), np.full(E, 3.0), z1, z2, refresh='step-O')
+    det, _ = O.mclachlan_step(_gauss_target, st, np.full(E, 0.1))
+    assert np.abs(b.position - det.position).max() == 0.0      # step-O does not touch positions
+    assert np.abs(a.position - det.position).max() > 0.0
+
+
+def test_integer_bookkeeping():
+    assert O.kept_indices(25, 10).tolist() == [0, 10, 20] and O.kept_indices(25, 10).dtype == np.int32
+    assert O.kept_indices(3, 1).tolist() == [0, 1, 2]
+    assert O.kept_indices(10000, 10)[-1] == 9990 and len(O.kept_indices(10000, 10)) == 1000
+    assert O.phase_steps(50000) == (40000, 5000, 5000) and O.phase_steps(57) == (45, 5, 5)
+    plan = O.train_plan(12, 4)
+    assert [p.tolist() for p in plan] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11]]
+    with pytest.raises(ValueError):
+        O.train_plan(12, 5)
+
+
+def test_desired_energy_var_schedules():
+    assert O.desired_energy_var(0, 101, 0.5, 0.1) == 0.5
+    assert abs(O.desired_energy_var(101, 101, 0.5, 0.1) - 0.1) < 1e-12
+    assert abs(O.desired_energy_var(500, 101, 0.5, 0.1) - 0.1) < 1e-12     # clamped progress
+    v = O.desired_energy_var(25, 101, 5.0, 0.1)                              # start > 2: exponential
+    assert abs(v - (5.0 * math.exp(-25 / 25.25) + 0.1 * (1 - math.exp(-25 / 25.25)))) < 1e-12
+
+
+def test_ess_on_ar1_and_white_noise():
+    rng = np.random.default_rng(6)
+    S = 20000
+    for phi in (0.0, 0.9):
+        x = np.zeros((1, S, 4))
+        e = rng.standard_normal((S, 4))
+        for t in range(1, S):
+            x[0, t] = phi * x[0, t - 1] + e[t]
+        ess = O.effective_sample_size(x)
+        assert np.abs(ess / (S * (1 - phi) / (1 + phi)) - 1).max() < 0.2
+
+
+def test_lppd_single_sample_is_mean_logpdf():
+    spec = O.ModelSpec(3, (4, 2))
+    rng = np.random.default_rng(7)
+    out = rng.standard_normal((1, 1, 9, 2))
+    y = rng.standard_normal(9)
+    pw = O.pointwise_lppd(spec, out, y)
+    sig = np.exp(out[0, 0, :, 1])
+    ref = (-0.5 * ((y - out[0, 0, :, 0]) / sig) ** 2 - np.log(sig) - 0.5 * math.log(2 * math.pi)).mean()
+    assert abs(O.lppd(pw) - ref) < 1e-12
+
+
+def test_tuner_runs_and_step_size_adapts_on_gaussian():
+    rng = np.random.default_rng(8)
+    E, d = 3, 30
+    st = O.mclmc_init(_gauss_target, rng.standard_normal((E, d)), rng.standard_normal((E, d)))
+    noise = lambda i: (rng.standard_normal((E, d)), rng.standard_normal((E, d)))
+    res = O.tune_phase12(_gauss_target, st, noise, 300, 60, step_size_init=0.01, desired_energy_var_start=0.5,
+                         desired_energy_var_end=0.1, trust_in_estimate=1.5, num_effective_samples=100)
+    assert np.all(res.step_size > 0.05) and np.all(np.isfinite(res.L))
+    assert np.abs(res.L / math.sqrt(d) - 1).max() < 0.5           # L = sqrt(sum Var) ~ sqrt(d) on N(0, I)
+    st2, L3 = O.tune_phase3(_gauss_target, res.state, res.step_size, res.L, noise, 200)
+    assert np.all(L3 > 0)
+
+
+@pytest.mark.parametrize('name,spec,refresh', [
+    ('regr_relu_8x8', O.ModelSpec(5, (8, 8, 2)), 'O-step-O'),
+    ('regr_relu_8x8_stepO', O.ModelSpec(5, (8, 8, 2)), 'step-O'),
+    ('class_tanh_6x4', O.ModelSpec(7, (6, 4), activation='tanh', task='classification', prior='Laplace', prior_scale=0.5), 'O-step-O'),
+    ('regr_relu_64x3', O.ModelSpec(5, (64, 64, 64, 2)), 'O-step-O'),
+])
+def test_oracle_reproduces_golden_vectors(name, spec, refresh):
+    z = np.load(GOLD / f'{name}.npz')
+    f = lambda th: O.logpost_and_grad(spec, th, z['X'], z['y'])
+    st = O.mclmc_init(f, z['theta0'].astype(np.float64), z['z0'].astype(np.float64))
+    assert np.allclose(st.logdensity, z['logp0'], rtol=1e-12, atol=0) and np.allclose(st.logdensity_grad, z['grad0'], rtol=1e-10, atol=1e-12)
+    T = z['noise'].shape[0]
+    for i in range(T):
+        st, info = O.mclmc_step(f, st, z['eps'].astype(np.float64), z['L'].astype(np.float64),
+                                z['noise'][i, 0].astype(np.float64), z['noise'][i, 1].astype(np.float64), refresh=refresh)
+        assert np.allclose(np.stack([info.logdensity, info.kinetic_change, info.energy_change], -1), z['info'][i], rtol=1e-9, atol=1e-9)
+    assert np.allclose(st.position, z[f'x_{T}'], rtol=1e-10, atol=1e-12)
+    assert np.allclose(st.momentum, z[f'u_{T}'], rtol=1e-9, atol=1e-12)
+
+
+def test_misc_golden():
+    z = np.load(GOLD / 'misc.npz')
+    assert np.array_equal(O.philox_bits(0x1234ABCD5678EF, z['philox_ids'], 9, 1, 37), z['philox_bits'])   # bit-exact
+    assert np.allclose(O.philox_normal(0x1234ABCD5678EF, z['philox_ids'], 9, 1, 37), z['philox_normal'], rtol=1e-13)
+    assert np.allclose(O.effective_sample_size(z['ar1']), z['ar1_ess'], rtol=1e-10)
+    assert abs(O.lppd(z['lppd_in']) - float(z['lppd_out'])) < 1e-13
