@@ -84,6 +84,7 @@ def main():
     ap.add_argument('--grad-kernel', default='auto')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--force-dist', action='store_true', help='init the process group even for 1 rank (rehearsal)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -96,11 +97,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device(f'cuda:{local_rank}')
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     # the oracle is imported here ONLY as workload generator (synthetic_problem) and for the
     # cpu_baseline leg; the timed path below never touches it
