@@ -170,8 +170,12 @@ def main():
         avg_s = ms * 1e-3 / max(n_launch, 1)
         achieved = flops / avg_s / 1e12
         info = eng.grad_launch_info(E)
+        traffic = None   # PMC counters cannot be read from inside the run: last committed measurement
+        tj = ROOT / 'profiles' / 'r01' / 'traffic.json'
+        if tj.exists() and E == E_PER_GPU and info['kernel'] == 'k_grad_w64':
+            traffic = json.loads(tj.read_text())['hbm_bytes_per_launch']
         roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
                 'kernel': info['kernel'], 'grid': list(info['grid']), 'lds_bytes': info['lds_bytes'],
                 'avg_launch_us': round(avg_s * 1e6, 2), 'launches_timed': n_launch,
                 'flop_per_launch': flops}
