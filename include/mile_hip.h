@@ -102,6 +102,36 @@ typedef struct mile_step_args {
   float *out_info;               /* [n_steps, E, 3] (logdensity, kinetic_change, energy_change) or NULL */
 } mile_step_args;
 
+/* Arguments of n_steps warm-up steps with on-device step-size adaptation == the scan body `step`
+ * of make_L_step_size_adaptation (src/training/warmup.py:271-363): kernel step, handle_nans
+ * (:468-483), the energy-variance step-size predictor, and the streaming averages of x and x^2
+ * that give L = sqrt(sum Var[x_i]) after tune2.  One tuner per chain; all arrays are device
+ * memory owned by the caller and updated in place. */
+typedef struct mile_tune_args {
+  float *step_size;              /* [E] in/out */
+  const float *L;                /* [E] */
+  const float *sqrt_diag_cov;    /* [E, d] or NULL */
+  float *step_size_max;          /* [E] in/out, start at +inf */
+  float *time;                   /* [E] in/out, start at 0 */
+  float *x_average;              /* [E] in/out, start at 0 */
+  float *stream_weight;          /* [E] in/out, start at 0 */
+  float *stream_average;         /* [E, 2, d] in/out, start at 0: weighted means of x and x^2 */
+  const float *noise;            /* [n_steps, 2, E, d] or NULL (counter RNG) */
+  uint64_t seed;
+  const int32_t *particle_ids;   /* [E] or NULL */
+  int64_t step_offset;           /* RNG step counter of the first step */
+  int32_t n_steps;
+  int32_t schedule_step0;        /* position of the first step in the schedule (0 .. tune1+tune2) */
+  int32_t n_mask_steps;          /* schedule positions < n_mask_steps are tune1 (mask = 1: no averaging) */
+  int32_t schedule_total;        /* tune1 + tune2 + 1 (warmup.py:251,259) */
+  float desired_energy_var_start;
+  float desired_energy_var_end;  /* linear decay, or exponential with tau = total/4 when start > 2 */
+  float trust_in_estimate;
+  float decay_rate;              /* (n_eff - 1) / (n_eff + 1) */
+  int32_t refresh;               /* mile_refresh */
+  float *out_info;               /* [n_steps, E, 3] or NULL */
+} mile_tune_args;
+
 typedef struct mile_sampler mile_sampler;
 
 const char *mile_last_error(void);
@@ -147,6 +177,11 @@ int32_t mile_init(mile_sampler *s, mile_state *state, const float *noise, uint64
  * (blackjax.mclmc(...).step == build_kernel(...)(rng_key, state, L, step_size),
  * src/training/warmup.py:286-291,427-432).  Advances `state` in place by n_steps. */
 int32_t mile_step(mile_sampler *s, mile_state *state, const mile_step_args *args, void *stream);
+
+/* Replaces: the lax.scan over `step` in make_L_step_size_adaptation.run_steps
+ * (src/training/warmup.py:352-363), i.e. phases 1+2 of mclmc_find_L_and_step_size, on the device.
+ * Advances `state` in place; supported for d <= 16384 (returns MILE_ERR_INVALID beyond). */
+int32_t mile_tune(mile_sampler *s, mile_state *state, const mile_tune_args *args, void *stream);
 
 /* Counter-RNG words/normals exactly as the step kernels draw them (test hook). out [E, d]. */
 int32_t mile_debug_noise(mile_sampler *s, uint64_t seed, const int32_t *particle_ids, int32_t E,

@@ -57,6 +57,19 @@ class StepArgsC(C.Structure):
     ]
 
 
+class TuneArgsC(C.Structure):
+    _fields_ = [
+        ('step_size', C.c_void_p), ('L', C.c_void_p), ('sqrt_diag_cov', C.c_void_p),
+        ('step_size_max', C.c_void_p), ('time', C.c_void_p), ('x_average', C.c_void_p),
+        ('stream_weight', C.c_void_p), ('stream_average', C.c_void_p), ('noise', C.c_void_p),
+        ('seed', C.c_uint64), ('particle_ids', C.c_void_p), ('step_offset', C.c_int64),
+        ('n_steps', C.c_int32), ('schedule_step0', C.c_int32), ('n_mask_steps', C.c_int32),
+        ('schedule_total', C.c_int32), ('desired_energy_var_start', C.c_float),
+        ('desired_energy_var_end', C.c_float), ('trust_in_estimate', C.c_float), ('decay_rate', C.c_float),
+        ('refresh', C.c_int32), ('out_info', C.c_void_p),
+    ]
+
+
 # name -> (restype, argtypes): every symbol include/mile_hip.h declares
 SIGNATURES = {
     'mile_last_error': (C.c_char_p, []),
@@ -72,6 +85,7 @@ SIGNATURES = {
     'mile_logpost_grad': (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     'mile_init': (C.c_int32, [C.c_void_p, C.POINTER(StateC), C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     'mile_step': (C.c_int32, [C.c_void_p, C.POINTER(StateC), C.POINTER(StepArgsC), C.c_void_p]),
+    'mile_tune': (C.c_int32, [C.c_void_p, C.POINTER(StateC), C.POINTER(TuneArgsC), C.c_void_p]),
     'mile_debug_noise': (C.c_int32, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int32, C.c_int64, C.c_int32,
                                      C.c_void_p, C.c_void_p]),
     'mile_grad_launch_info': (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),

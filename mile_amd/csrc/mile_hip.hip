@@ -38,6 +38,7 @@ struct mile_sampler {
   // workspace
   int E_cap = 0, S_cap = 0;
   float *slabs = nullptr, *llpart = nullptr, *dK = nullptr, *lold = nullptr;
+  float *alt_x = nullptr, *alt_u = nullptr, *alt_g = nullptr, *alt_logp = nullptr;   // ping-pong state of mile_tune
   int grad_kernel = MILE_GRAD_AUTO;
   // timing of grad launches
   bool timing = false;
@@ -159,6 +160,11 @@ static void free_ws(mile_sampler *s) {
   if (s->llpart) (void)hipFree(s->llpart);
   if (s->dK) (void)hipFree(s->dK);
   if (s->lold) (void)hipFree(s->lold);
+  if (s->alt_x) (void)hipFree(s->alt_x);
+  if (s->alt_u) (void)hipFree(s->alt_u);
+  if (s->alt_g) (void)hipFree(s->alt_g);
+  if (s->alt_logp) (void)hipFree(s->alt_logp);
+  s->alt_x = s->alt_u = s->alt_g = s->alt_logp = nullptr;
   s->slabs = s->llpart = s->dK = s->lold = nullptr;
   s->E_cap = s->S_cap = 0;
 }
@@ -224,6 +230,10 @@ int32_t mile_reserve(mile_sampler *s, int32_t E) {
   HIP_TRY(hipMalloc(&s->llpart, (size_t)E * S * 4));
   HIP_TRY(hipMalloc(&s->dK, (size_t)E * 4));
   HIP_TRY(hipMalloc(&s->lold, (size_t)E * 4));
+  HIP_TRY(hipMalloc(&s->alt_x, (size_t)E * s->ds.d * 4));
+  HIP_TRY(hipMalloc(&s->alt_u, (size_t)E * s->ds.d * 4));
+  HIP_TRY(hipMalloc(&s->alt_g, (size_t)E * s->ds.d * 4));
+  HIP_TRY(hipMalloc(&s->alt_logp, (size_t)E * 4));
   s->E_cap = E;
   s->S_cap = S;
   return MILE_OK;
@@ -268,7 +278,7 @@ static void launch_update(const UpdParams &u, int E, hipStream_t st) {
   }
   // every row base is (pointer + e*d): vector width allowed by d and by the pointers
   int al = (u.d % 4 == 0) ? 4 : ((u.d % 2 == 0) ? 2 : 1);
-  const void *ptrs[] = {u.x, u.u, u.g, u.slabs, u.sdc, u.zA, u.zB, u.out_sample};
+  const void *ptrs[] = {u.x, u.u, u.g, u.slabs, u.sdc, u.zA, u.zB, u.out_sample, u.x_in, u.u_in, u.g_in, u.t_avg};
   for (const void *q : ptrs)
     if (q) al = std::min(al, ptr_align(q));
   const int nk = (nqf + UPD_NT - 1) / UPD_NT;
@@ -489,6 +499,98 @@ int32_t mile_step(mile_sampler *s, mile_state *state, const mile_step_args *a, v
       }
       launch_update(u, E, st);
     }
+  }
+  HIP_TRY(hipGetLastError());
+  return MILE_OK;
+}
+
+int32_t mile_tune(mile_sampler *s, mile_state *state, const mile_tune_args *a, void *stream) {
+  if (!s || !state || !a) return fail(MILE_ERR_INVALID, "mile_tune: null argument");
+  if (!state->position || !state->momentum || !state->logdensity || !state->logdensity_grad)
+    return fail(MILE_ERR_INVALID, "mile_tune: null state field");
+  if (!a->step_size || !a->L || !a->step_size_max || !a->time || !a->x_average || !a->stream_weight || !a->stream_average)
+    return fail(MILE_ERR_INVALID, "mile_tune: null tuner array");
+  if (a->n_steps < 0 || a->schedule_total < 1) return fail(MILE_ERR_INVALID, "mile_tune: bad step counts");
+  if (a->refresh != MILE_REFRESH_O_STEP_O && a->refresh != MILE_REFRESH_STEP_O)
+    return fail(MILE_ERR_INVALID, "mile_tune: unknown refresh mode");
+  const int E = state->n_particles, d = s->ds.d;
+  if (E < 1) return fail(MILE_ERR_INVALID, "mile_tune: n_particles must be >= 1");
+  if ((d >> 2) < 1 || (d >> 2) > UPD_NT * UPD_QMAX)
+    return fail(MILE_ERR_INVALID, "mile_tune: the on-device tuner supports 4 <= d <= 16384");
+  if (a->n_steps == 0) return MILE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipSetDevice(s->device));
+  if (!s->X) return fail(MILE_ERR_STATE, "no data: call mile_set_data first");
+  const int S = choose_S(s, E, resolved_kernel(s));
+  if (E > s->E_cap || S > s->S_cap) return fail(MILE_ERR_STATE, "workspace too small: call mile_reserve(E) first");
+
+  struct Buf { float *x, *u, *g, *logp; };
+  const Buf A{state->position, state->momentum, state->logdensity_grad, state->logdensity};
+  const Buf B{s->alt_x, s->alt_u, s->alt_g, s->alt_logp};
+  UpdParams up{};
+  up.d = d; up.E = E; up.S = S;
+  up.prior = s->ds.prior; up.prior_loc = s->ds.prior_loc; up.prior_scale = s->ds.prior_scale;
+  up.slabs = s->slabs; up.llpart = s->llpart;
+  up.eps = a->step_size; up.L = a->L; up.sdc = a->sqrt_diag_cov;
+  up.seed = a->seed; up.pids = a->particle_ids;
+  up.dK = s->dK; up.lold = s->lold;
+  const float b1 = (float)MCLACHLAN_B1, b2 = (float)(1.0 - 2.0 * MCLACHLAN_B1);
+  const bool oso = a->refresh == MILE_REFRESH_O_STEP_O;
+  const size_t Ed = (size_t)E * d;
+  auto noise_at = [&](int i, int k) -> const float * { return a->noise ? a->noise + ((size_t)i * 2 + k) * Ed : nullptr; };
+  auto set_state = [](UpdParams &u, const Buf &b) { u.x = b.x; u.u = b.u; u.g = b.g; u.logp = b.logp; };
+
+  for (int i = 0; i < a->n_steps; ++i) {
+    const Buf &cur = (i & 1) ? B : A, &nxt = (i & 1) ? A : B;
+    const int64_t gstep = a->step_offset + i;
+    {  // O(z1) . B(b1) . A(1/2): reads the current state, writes the other buffer (free backup)
+      UpdParams u = up;
+      set_state(u, nxt);
+      u.x_in = cur.x; u.u_in = cur.u; u.g_in = cur.g; u.logp_in = cur.logp;
+      u.flags = UPD_START | UPD_B2 | UPD_A | (oso ? UPD_OB : 0);
+      u.zB = noise_at(i, 0); u.stepB = (uint32_t)gstep; u.stageB = 0; u.hB = 0.5f;
+      u.coef_b2 = b1; u.coef_a = 0.5f;
+      launch_update(u, E, st);
+    }
+    int rc = launch_grad(s, nxt.x, E, st);
+    if (rc) return rc;
+    {
+      UpdParams u = up;
+      set_state(u, nxt);
+      u.flags = UPD_FROM_SLABS | UPD_B1 | UPD_A;
+      u.coef_b1 = b2; u.coef_a = 0.5f;
+      launch_update(u, E, st);
+    }
+    rc = launch_grad(s, nxt.x, E, st);
+    if (rc) return rc;
+    {  // B(b1) . O(z2) . record + tuner (step-size predictor, handle_nans, streaming averages)
+      UpdParams u = up;
+      set_state(u, nxt);
+      u.flags = UPD_FROM_SLABS | UPD_B1 | UPD_OA | UPD_RECORD | UPD_TUNE;
+      u.coef_b1 = b1;
+      u.zA = noise_at(i, 1); u.stepA = (uint32_t)gstep; u.stageA = 1; u.hA = oso ? 0.5f : 1.0f;
+      u.bk_x = cur.x; u.bk_u = cur.u; u.bk_g = cur.g; u.bk_logp = cur.logp;
+      u.t_eps = a->step_size; u.t_eps_max = a->step_size_max; u.t_time = a->time; u.t_xavg = a->x_average;
+      u.t_W = a->stream_weight; u.t_avg = a->stream_average;
+      const int sp = a->schedule_step0 + i;
+      u.t_mask = sp < a->n_mask_steps ? 1.0f : 0.0f;
+      const double tot = (double)a->schedule_total, vs = a->desired_energy_var_start, ve = a->desired_energy_var_end;
+      if (vs > 2.0) {
+        const double tau = tot / 4.0, ex = std::exp(-(double)sp / tau);
+        u.t_var = (float)(vs * ex + ve * (1.0 - ex));
+      } else {
+        u.t_var = (float)(vs - (vs - ve) * std::min((double)sp / tot, 1.0));
+      }
+      u.t_trust = a->trust_in_estimate; u.t_decay = a->decay_rate;
+      if (a->out_info) u.out_info = a->out_info + (size_t)i * E * 3;
+      launch_update(u, E, st);
+    }
+  }
+  if (a->n_steps & 1) {   // the final state sits in the library's buffer
+    HIP_TRY(hipMemcpyAsync(A.x, B.x, Ed * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(A.u, B.u, Ed * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(A.g, B.g, Ed * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(A.logp, B.logp, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
   }
   HIP_TRY(hipGetLastError());
   return MILE_OK;

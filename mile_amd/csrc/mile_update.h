@@ -24,6 +24,7 @@ enum : int32_t {
   UPD_OB = 1 << 5,          // O with noise B after the record point
   UPD_B2 = 1 << 6,          // B(coef_b2) after the record point
   UPD_A = 1 << 7,           // position update with coef_a
+  UPD_TUNE = 1 << 8,        // record point also runs the warm-up tuner (k_update_fast only)
 };
 
 struct UpdParams {
@@ -42,6 +43,17 @@ struct UpdParams {
   float *dK, *lold;              // workspace [E]
   float *out_sample;             // [E, d] or NULL
   float *out_info;               // [E, 3] or NULL
+  // separate inputs (ping-pong state): NULL -> read from x/u/g/logp (in place)
+  const float *x_in, *u_in, *g_in, *logp_in;
+  // ---- warm-up tuner (UPD_TUNE): make_L_step_size_adaptation, src/training/warmup.py:271-350 ----
+  float *t_eps;                  // [E] step size, rewritten at the record point
+  float *t_eps_max, *t_time, *t_xavg;   // [E] adaptive state (step_size_max, time, x_average)
+  float *t_W;                    // [E] streaming-average weight
+  float *t_avg;                  // [E, 2, d] streaming averages of x and x^2
+  const float *bk_x, *bk_u, *bk_g, *bk_logp;   // state before this kernel step (handle_nans reverts to it)
+  float t_mask;                  // 1 during tune1 (no averaging), 0 during tune2
+  float t_var;                   // desired energy variance at this step
+  float t_trust, t_decay;
 };
 
 // B / O chain on the coefficients of {u, e, zA, zB}; norms and projections come from the
@@ -89,7 +101,7 @@ struct Chain {
 
 #define UPD_NT 1024
 #define UPD_NW (UPD_NT / 64)
-#define UPD_NSUM 11
+#define UPD_NSUM 12   // 10 dot products, log-prior, non-finite count
 #define UPD_QMAX 4   // quads a thread keeps in registers between the passes (d <= 16384)
 
 // CACHED: every thread keeps its <= UPD_QMAX quads of (x, u, g~, zA, zB) in registers between
@@ -320,6 +332,8 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
   const bool explA = useA && p.zA, explB = useB && p.zB;
   const uint32_t pid = p.pids ? (uint32_t)p.pids[e] : (uint32_t)e;
   const float *sl = p.slabs + (size_t)e * p.S * d;
+  const float *xin = p.x_in ? p.x_in : p.x, *uin = p.u_in ? p.u_in : p.u, *gin = p.g_in ? p.g_in : p.g;
+  const bool tune = p.flags & UPD_TUNE;
   const float ips = 1.0f / p.prior_scale;
   const bool normal = p.prior == MILE_PRIOR_NORMAL;
 
@@ -330,14 +344,14 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
     const int q = tid + k * UPD_NT;
     const bool valid = q < nqf;
     const size_t o = base + 4 * (size_t)(valid ? q : 0);
-    cx[k] = ld4<AL>(p.x + o);
-    cu[k] = ld4<AL>(p.u + o);
+    cx[k] = ld4<AL>(xin + o);
+    cu[k] = ld4<AL>(uin + o);
     if (from_slabs) {
       f32x4 g = ld4<AL>(sl + (o - base));
       for (int s = 1; s < p.S; ++s) g += ld4<AL>(sl + (size_t)s * d + (o - base));
       cg[k] = g;
     } else {
-      cg[k] = ld4<AL>(p.g + o);
+      cg[k] = ld4<AL>(gin + o);
     }
     if constexpr (SDC) csd[k] = ld4<AL>(p.sdc + o);
     ca[k] = explA ? ld4<AL>(p.zA + o) : f32x4{0, 0, 0, 0};
@@ -349,9 +363,9 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
   float tx = 0, tu = 0, tg = 0, ta = 0, tb = 0, tsd = 1.0f;
   if (ntail) {
     const size_t tc = has_tail ? to : base;
-    tx = p.x[tc]; tu = p.u[tc];
+    tx = xin[tc]; tu = uin[tc];
     if (from_slabs) { tg = 0.0f; for (int s = 0; s < p.S; ++s) tg += sl[(size_t)s * d + (tc - base)]; }
-    else tg = p.g[tc];
+    else tg = gin[tc];
     if (SDC) tsd = p.sdc[tc];
     if (explA) ta = p.zA[tc];
     if (explB) tb = p.zB[tc];
@@ -376,6 +390,7 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
         else { gi -= (t > 0.0f ? ips : (t < 0.0f ? -ips : 0.0f)); sm[10] -= mk * fabsf(t); }
       }
       cg[k][m] = gi;                       // un-preconditioned gradient (stored below)
+      if (tune) sm[11] += (mk != 0.0f && !isfinite(xi)) ? 1.0f : 0.0f;
       const float gs = (SDC ? gi * csd[k][m] : gi) * mk;
       const float ui = cu[k][m] * mk, a = ca[k][m] * mk, b = cb[k][m] * mk;
       ca[k][m] = a; cb[k][m] = b;
@@ -404,6 +419,7 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
       else { tg -= (tt > 0.0f ? ips : (tt < 0.0f ? -ips : 0.0f)); sm[10] -= mk * fabsf(tt); }
       if (has_tail) p.g[to] = tg;
     }
+    if (tune) sm[11] += (has_tail && !isfinite(tx)) ? 1.0f : 0.0f;
     tg *= tsd;
     const float gs = tg * mk, ui = tu * mk;
     ta *= mk; tb *= mk;
@@ -439,7 +455,7 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
                              : -(float)d * logf(2.0f * p.prior_scale);
     logp_now = ll + (S[10] + cst);
   } else {
-    logp_now = p.logp[e];
+    logp_now = (p.logp_in ? p.logp_in : p.logp)[e];
   }
   const float gn = S[2] > 0.0f ? sqrtf(S[2]) : 1.0f;
   const float ign = 1.0f / gn;
@@ -465,13 +481,43 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
     dk = 0.0f;
     lold = logp_now;
   }
+  // ---- warm-up tuner at the record point (predictor + handle_nans, warmup.py:271-326,468-483) ----
+  bool t_ok = true;
+  float t_wgt = 0.0f, t_Wold = 0.0f;
+  if (tune) {
+    constexpr float FMAX = 3.4028234663852886e38f;
+    t_ok = S[11] == 0.0f;                                   // jnp.all(jnp.isfinite(position))
+    float dE = info_de;
+    dE = t_ok ? (isnan(dE) ? 0.0f : fminf(fmaxf(dE, -FMAX), FMAX)) : 0.0f;          // nan_to_num / 0.0
+    const float emax_old = p.t_eps_max[e];
+    const float emax = t_ok ? fminf(emax_old, FMAX) : 0.8f * eps;                   // nan_to_num(inf) = FLT_MAX
+    const float xi = dE * dE / ((float)d * p.t_var) + 1e-8f;
+    const float lx = logf(xi) / (6.0f * p.t_trust);
+    const float w = expf(-0.5f * lx * lx);
+    const float e2 = eps * eps;
+    const float xavg = p.t_decay * p.t_xavg[e] + w * (xi / (e2 * e2 * e2));
+    const float tm = p.t_decay * p.t_time[e] + w;
+    float en = powf(xavg / tm, -1.0f / 6.0f);
+    en = (en < emax ? 1.0f : 0.0f) * en + (en > emax ? 1.0f : 0.0f) * emax;         // as written at warmup.py:317-319 (0 * inf = NaN included)
+    t_Wold = p.t_W[e];
+    t_wgt = (1.0f - p.t_mask) * (t_ok ? 1.0f : 0.0f) * en;
+    if (!t_ok) logp_now = p.bk_logp[e];
+    __syncthreads();                                        // everyone has read the adaptive state
+    if (tid == 0) {
+      p.t_eps[e] = en;
+      p.t_eps_max[e] = emax;
+      p.t_xavg[e] = xavg;
+      p.t_time[e] = tm;
+      p.t_W[e] = t_Wold + t_wgt;
+    }
+  }
   if (p.flags & UPD_OB) ch.O(3, p.hB * eps, L, d);
   if (p.flags & UPD_B2) dk += ch.B(eps, p.coef_b2, gn, d);
   __syncthreads();
   if (tid == 0) {
     p.dK[e] = dk;
     p.lold[e] = lold;
-    if (from_slabs) p.logp[e] = logp_now;
+    if (from_slabs || tune) p.logp[e] = logp_now;
     if ((p.flags & UPD_RECORD) && p.out_info) {
       p.out_info[3 * e + 0] = logp_now;
       p.out_info[3 * e + 1] = info_dk;
@@ -483,11 +529,32 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
   const bool doA = p.flags & UPD_A;
   const float c0 = ch.c[0], c1 = ch.c[1] * ign, c2 = ch.c[2], c3 = ch.c[3];
   const float ea = eps * p.coef_a;
+  if (tune && !t_ok) {   // handle_nans: this chain keeps its previous state (rare, workgroup-uniform)
+    for (int i = tid; i < d; i += UPD_NT) {
+      p.x[base + i] = p.bk_x[base + i];
+      p.u[base + i] = p.bk_u[base + i];
+      p.g[base + i] = p.bk_g[base + i];
+    }
+    return;
+  }
+  const bool t_acc = tune && p.t_mask == 0.0f;              // streaming_average_update of [x, x^2]
+  const float t_den = 1.0f / (t_Wold + t_wgt);              // zero_prevention = mask = 0 here
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
     const int q = tid + k * UPD_NT;
     if (q < nqf) {
       const size_t o = base + 4 * (size_t)q;
+      if (t_acc) {
+        float *a0 = p.t_avg + (size_t)e * 2 * d + 4 * (size_t)q, *a1 = a0 + d;
+        f32x4 m0 = ld4<AL>(a0), m1 = ld4<AL>(a1);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          m0[m] = (t_Wold * m0[m] + t_wgt * cx[k][m]) * t_den;
+          m1[m] = (t_Wold * m1[m] + t_wgt * cx[k][m] * cx[k][m]) * t_den;
+        }
+        st4<AL>(a0, m0);
+        st4<AL>(a1, m1);
+      }
       f32x4 v = cu[k];
       if (any_op) {
 #pragma unroll
@@ -504,6 +571,11 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
     }
   }
   if (has_tail) {
+    if (t_acc) {
+      float *a0 = p.t_avg + (size_t)e * 2 * d + 4 * (size_t)nqf + tid, *a1 = a0 + d;
+      *a0 = (t_Wold * *a0 + t_wgt * tx) * t_den;
+      *a1 = (t_Wold * *a1 + t_wgt * tx * tx) * t_den;
+    }
     float v = tu;
     if (any_op) { v = fmaf(c0, tu, fmaf(c1, tg, fmaf(c2, ta, c3 * tb))); p.u[to] = v; }
     if (p.out_sample) p.out_sample[to] = tx;

@@ -238,6 +238,57 @@ class Engine:
         inf = MCLMCInfo(info[..., 0], info[..., 1], info[..., 2]) if info is not None else None
         return state, inf, samples
 
+    def tune(self, state: IntegratorState, tuner: dict, L, n_steps: int, *, schedule_step0: int, n_mask_steps: int,
+             schedule_total: int, desired_energy_var_start: float, desired_energy_var_end: float,
+             trust_in_estimate: float, decay_rate: float, noise=None, seed: int = 0, step_offset: int = 0,
+             particle_ids=None, refresh: str = 'O-step-O', sqrt_diag_cov=None, want_info: bool = False):
+        """n_steps warm-up steps with on-device step-size adaptation (mile_tune).  ``state`` and the
+        ``tuner`` tensors (step_size, step_size_max, time, x_average, stream_weight [E];
+        stream_average [E, 2, d]) are advanced IN PLACE.  Returns MCLMCInfo or None."""
+        E, dev = state.position.shape[0], self.device
+        for t in tuple(state) + tuple(tuner.values()):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
+                raise ValueError('state / tuner tensors must be contiguous fp32 on the engine device')
+        if tuner['stream_average'].shape != (E, 2, self.d):
+            raise ValueError('stream_average must be [E, 2, d]')
+        self.reserve(E)
+        Lt = _f32(L, dev).expand(E).contiguous() if torch.as_tensor(L).ndim == 0 else _f32(L, dev, (E,), 'L')
+        z = _f32(noise, dev, (n_steps, 2, E, self.d), 'noise') if noise is not None else None
+        sdc = _f32(sqrt_diag_cov, dev, (E, self.d), 'sqrt_diag_cov') if sqrt_diag_cov is not None else None
+        ids = self._ids(particle_ids, E)
+        info = torch.empty((n_steps, E, 3), dtype=torch.float32, device=dev) if want_info else None
+        a = _lib.TuneArgsC()
+        a.step_size = tuner['step_size'].data_ptr()
+        a.L = Lt.data_ptr()
+        a.sqrt_diag_cov = sdc.data_ptr() if sdc is not None else None
+        a.step_size_max = tuner['step_size_max'].data_ptr()
+        a.time = tuner['time'].data_ptr()
+        a.x_average = tuner['x_average'].data_ptr()
+        a.stream_weight = tuner['stream_weight'].data_ptr()
+        a.stream_average = tuner['stream_average'].data_ptr()
+        a.noise = z.data_ptr() if z is not None else None
+        a.seed = seed
+        a.particle_ids = ids.data_ptr() if ids is not None else None
+        a.step_offset = step_offset
+        a.n_steps = n_steps
+        a.schedule_step0 = schedule_step0
+        a.n_mask_steps = n_mask_steps
+        a.schedule_total = schedule_total
+        a.desired_energy_var_start = desired_energy_var_start
+        a.desired_energy_var_end = desired_energy_var_end
+        a.trust_in_estimate = trust_in_estimate
+        a.decay_rate = decay_rate
+        a.refresh = _lib.REFRESH_IDS[refresh]
+        a.out_info = info.data_ptr() if info is not None else None
+        sc = self._state_c(state)
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.mile_tune(self._h, C.byref(sc), C.byref(a), self._stream()), self.lib)
+        return MCLMCInfo(info[..., 0], info[..., 1], info[..., 2]) if info is not None else None
+
+    @property
+    def supports_device_tuner(self) -> bool:
+        return 4 <= self.d <= 16384
+
     def debug_noise(self, seed: int, E: int, step: int, stage: int, particle_ids=None):
         ids = self._ids(particle_ids, E)
         out = torch.empty((E, self.d), dtype=torch.float32, device=self.device)

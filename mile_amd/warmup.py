@@ -4,7 +4,9 @@ all chains advanced together on the device.
 The arithmetic per chain is exactly the reference's (phase 1+2: step size from the energy
 variance with a decaying target and the streaming x / x^2 averages -> L; phase 3: L from the
 FFT effective sample size).  The kernel step is libmile_hip's; the per-chain scalar updates
-are torch ops on [E] device tensors enqueued on the same stream, so the loop never syncs.
+run on the device too: phases 1+2 inside libmile_hip (mile_tune: the step-size predictor,
+handle_nans and the streaming averages are part of the record-point update kernel); a host-driven
+loop of torch ops on [E] tensors is kept for d > 16384.
 """
 from __future__ import annotations
 
@@ -84,7 +86,7 @@ def streaming_average_update(value, weight_and_avg, weight, zero_prevention):
 def mclmc_find_L_and_step_size(eng, state: IntegratorState, rng_key, *, tune1_steps, tune2_steps, tune3_steps,
                                step_size_init, desired_energy_var_start, desired_energy_var_end,
                                trust_in_estimate, num_effective_samples, diagonal_preconditioning,
-                               chain_ids=None, refresh='O-step-O', noise_fn=None, param_subset=None,
+                               chain_ids=None, refresh='O-step-O', noise_fn=None, param_subset=None, force_host_loop=False,
                                Lfactor=0.4, fft_params_limit=2000, fft_samples_limit=10000):
     """warmup.py:155-228 for an ensemble.  ``noise_fn(i) -> [2, E, d]`` switches to explicit noise
     (parity tests); ``param_subset`` [E, <=2000] replaces jax.random.permutation in phase 3."""
@@ -99,7 +101,27 @@ def mclmc_find_L_and_step_size(eng, state: IntegratorState, rng_key, *, tune1_st
     decay_rate = (num_effective_samples - 1.0) / (num_effective_samples + 1.0)
     total = tune1_steps + tune2_steps + 1
 
-    def run_steps(state, eps, masks, seed, offset):
+    def run_steps_device(state, eps, masks, seed, offset, chunk=256):
+        """The scan of `step` on the device (mile_tune): adaptation state stays in HBM, no host loop
+        per step.  Fresh adaptive state per call, exactly as run_steps does (warmup.py:352-363)."""
+        tuner = {'step_size': eps.clone(), 'step_size_max': torch.full((E,), float('inf'), **f32),
+                 'time': torch.zeros(E, **f32), 'x_average': torch.zeros(E, **f32),
+                 'stream_weight': torch.zeros(E, **f32), 'stream_average': torch.zeros((E, 2, d), **f32)}
+        state = IntegratorState(*(t.clone() for t in state))
+        n_mask = sum(1 for m in masks if m == 1.0)
+        assert all(m == 1.0 for m in masks[:n_mask]) and all(m == 0.0 for m in masks[n_mask:])
+        done = 0
+        while done < len(masks):
+            c = min(chunk, len(masks) - done)
+            z = torch.stack([noise_fn(offset + done + i) for i in range(c)]) if noise_fn is not None else None
+            eng.tune(state, tuner, L_cur[0], c, schedule_step0=done, n_mask_steps=n_mask, schedule_total=total,
+                     desired_energy_var_start=desired_energy_var_start, desired_energy_var_end=desired_energy_var_end,
+                     trust_in_estimate=trust_in_estimate, decay_rate=decay_rate, noise=z, seed=seed,
+                     step_offset=offset + done, particle_ids=chain_ids, refresh=refresh, sqrt_diag_cov=sdc_cur[0])
+            done += c
+        return state, tuner['step_size'], tuner['stream_average']
+
+    def run_steps_host(state, eps, masks, seed, offset):
         time = torch.zeros(E, **f32)
         x_avg = torch.zeros(E, **f32)
         eps_max = torch.full((E,), float('inf'), **f32)
@@ -120,6 +142,7 @@ def mclmc_find_L_and_step_size(eng, state: IntegratorState, rng_key, *, tune1_st
                                                   zero_prevention=torch.zeros(E, **f32))
         return state, eps, avg
 
+    run_steps = run_steps_device if (eng.supports_device_tuner and not force_host_loop) else run_steps_host
     L_cur, sdc_cur = [L], [sdc]
     masks = [1.0] * tune1_steps + [0.0] * tune2_steps
     state, eps, avg = run_steps(state, eps, masks, part1_key.seed, 0)

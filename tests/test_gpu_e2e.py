@@ -176,6 +176,85 @@ def test_warmup_tuner_matches_oracle_with_explicit_noise(oracle):
     assert params.sqrt_diag_cov.shape == (E, d) and torch.all(params.sqrt_diag_cov == 1)
 
 
+def test_device_tuner_matches_host_loop(oracle):
+    """mile_tune (phases 1+2 on the device) == the host-driven loop over mile_step with the same noise."""
+    from mile_amd.warmup import mclmc_find_L_and_step_size
+    ospec = oracle.ModelSpec(5, (64, 64, 64, 2))
+    E, d = 4, ospec.n_params
+    prob = oracle.synthetic_problem(ospec, 100, E, seed=5)
+    rng = np.random.default_rng(3)
+    t1, t2 = 9, 4
+    z0 = torch.from_numpy(rng.standard_normal((E, d)).astype(np.float32))
+    n12 = torch.from_numpy(rng.standard_normal((t1 + t2, 2, E, d)).astype(np.float32)).cuda()
+    eng = _engine(ospec, prob['X'], prob['y'])
+    kw = dict(tune1_steps=t1, tune2_steps=t2, tune3_steps=0, step_size_init=0.002, desired_energy_var_start=0.5,
+              desired_energy_var_end=0.1, trust_in_estimate=1.5, num_effective_samples=100,
+              diagonal_preconditioning=False, noise_fn=lambda i: n12[i])
+    out = {}
+    for host in (True, False):
+        s0 = eng.init(torch.from_numpy(prob['theta0']), noise=z0)
+        out[host] = mclmc_find_L_and_step_size(eng, s0, 0, force_host_loop=host, **kw)
+    (sh, ph), (sd, pd) = out[True], out[False]
+    assert _rel(pd.step_size.cpu(), ph.step_size.cpu()) < 2e-3
+    assert _rel(pd.L.cpu(), ph.L.cpu()) < 2e-3
+    assert _rel(sd.position.cpu(), sh.position.cpu()) < 1e-3
+    assert _rel(sd.logdensity.cpu(), sh.logdensity.cpu()) < 1e-4
+    # diagonal preconditioning branch: sqrt_diag_cov from the tune2 variances, L = sqrt(d), extra steps
+    kw['diagonal_preconditioning'] = True
+    kw['step_size_init'] = 0.05
+    n_extra = torch.from_numpy(rng.standard_normal((t1 + t2 + t2 // 3, 2, E, d)).astype(np.float32)).cuda()
+    kw['noise_fn'] = lambda i: n_extra[i]
+    outp = {}
+    for host in (True, False):
+        s0 = eng.init(torch.from_numpy(prob['theta0']), noise=z0)
+        outp[host] = mclmc_find_L_and_step_size(eng, s0, 0, force_host_loop=host, **kw)
+    # Var = E[x^2] - E[x]^2 in fp32 over a handful of barely-moved samples can cancel to <= 0 (NaN after sqrt)
+    # in the reference arithmetic too: compare where both are finite and well above the cancellation floor
+    a, b = outp[False][1].sqrt_diag_cov.cpu().numpy(), outp[True][1].sqrt_diag_cov.cpu().numpy()
+    good = np.isfinite(a) & np.isfinite(b) & (b > 5e-3)
+    assert good.mean() > 0.5 and np.abs(a[good] - b[good]).max() / b[good].max() < 2e-2
+    assert torch.allclose(outp[False][1].L.cpu(), torch.full((E,), math.sqrt(d)))
+    # one re-adjustment step with a ~1e-2 preconditioner moves eps by four orders of magnitude: 5 %
+    assert _rel(outp[False][1].step_size.cpu(), outp[True][1].step_size.cpu()) < 5e-2
+
+
+def test_device_tuner_rejects_nonfinite_steps(oracle):
+    """handle_nans on the device: a chain whose step leaves the finite numbers keeps its state and gets
+    step_size_max = 0.8 eps; the other chains follow the predictor formula."""
+    from mile_amd.warmup import predictor_update
+    ospec = oracle.ModelSpec(5, (16, 16, 2))
+    E, d = 3, ospec.n_params
+    prob = oracle.synthetic_problem(ospec, 80, E, seed=6)
+    th = prob['theta0'].copy()
+    th[1] = 1e18                                              # chain 1: the forward pass overflows -> NaN gradient
+    eng = _engine(ospec, prob['X'], prob['y'])
+    s0 = eng.init(torch.from_numpy(th), seed=1)
+    st = type(s0)(*(t.clone() for t in s0))
+    f32 = dict(dtype=torch.float32, device='cuda')
+    eps0 = torch.full((E,), 1e-3, **f32)
+    tuner = {'step_size': eps0.clone(), 'step_size_max': torch.full((E,), float('inf'), **f32),
+             'time': torch.zeros(E, **f32), 'x_average': torch.zeros(E, **f32),
+             'stream_weight': torch.zeros(E, **f32), 'stream_average': torch.zeros((E, 2, d), **f32)}
+    info = eng.tune(st, tuner, torch.full((E,), 20.0), 1, schedule_step0=0, n_mask_steps=0, schedule_total=10,
+                    desired_energy_var_start=0.5, desired_energy_var_end=0.1, trust_in_estimate=1.5,
+                    decay_rate=99 / 101, seed=1, want_info=True)
+    torch.cuda.synchronize()
+    assert torch.equal(st.position[1], s0.position[1])                       # reverted
+    assert not torch.equal(st.position[0], s0.position[0]) and torch.isfinite(st.position[[0, 2]]).all()
+    assert tuner['step_size_max'][1].item() == pytest.approx(0.8e-3, rel=1e-6)
+    assert tuner['step_size_max'][0].item() > 3e38                            # nan_to_num(inf)
+    assert tuner['stream_weight'][1].item() == 0.0 and tuner['stream_weight'][0].item() > 0.0
+    dE = info.energy_change[0].clone()
+    dE[1] = 0.0                                                               # rejected: energy change 0.0
+    ref, _, _ = predictor_update(dE, eps0, torch.zeros(E, **f32), torch.zeros(E, **f32), tuner['step_size_max'],
+                                 dim=d, desired_var=0.5, trust_in_estimate=1.5, decay_rate=99 / 101)
+    assert _rel(tuner['step_size'].cpu(), ref.cpu()) < 1e-4
+    assert tuner['step_size'][1].item() == pytest.approx(0.8e-3, rel=1e-5)    # clipped at step_size_max
+    # streaming average after one accepted tune2 step is the position itself
+    assert torch.allclose(tuner['stream_average'][0, 0], st.position[0])
+    assert torch.allclose(tuner['stream_average'][0, 1], st.position[0] ** 2)
+
+
 def test_inference_loop_writes_reference_layout(oracle, tmp_path):
     from mile_amd.callbacks import load_samples_from_dir
     from mile_amd.config import SamplerConfig

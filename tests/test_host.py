@@ -29,8 +29,11 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert lib.mile_abi_version() == _lib.ABI_VERSION
     # struct layouts agree with the header's field order
-    assert [f[0] for f in _lib.StepArgsC._fields_] == re.findall(r'^\s+(?:const\s+)?\w+\s*\*?\s*(\w+);', re.search(
-        r'typedef struct mile_step_args \{(.*?)\} mile_step_args;', header, re.S).group(1), re.M)
+    for cls, name in ((_lib.StepArgsC, 'mile_step_args'), (_lib.TuneArgsC, 'mile_tune_args'),
+                      (_lib.StateC, 'mile_state'), (_lib.ModelSpecC, 'mile_model_spec')):
+        body = re.sub(r'/\*.*?\*/', '', re.search(r'typedef struct %s \{(.*?)\} %s;' % (name, name), header, re.S).group(1), flags=re.S)
+        fields = re.findall(r'(?:const\s+)?\w+\s*\*?\s*(\w+)(?:\[\w+\])?\s*;', body)
+        assert [f[0] for f in cls._fields_] == fields, name
 
 
 def test_host_calls_that_need_no_gpu():
