@@ -7,7 +7,17 @@ from pathlib import Path
 import numpy as np
 
 from mile_amd.spec import ModelSpec
-from mile_amd.tree import get_flattened_keys
+
+
+def get_flattened_keys(d: dict, sep: str = '.') -> list[str]:
+    """src/utils.py:50-70: dotted paths of the leaves, dict order."""
+    keys = []
+    for k, v in d.items():
+        if isinstance(v, dict):
+            keys.extend([f'{k}{sep}{kk}' for kk in get_flattened_keys(v)])
+        else:
+            keys.append(k)
+    return keys
 
 
 def save_position(position: dict, base: Path, idx, n: int):

@@ -10,13 +10,14 @@ from __future__ import annotations
 
 import logging
 import pickle
-from concurrent.futures import ThreadPoolExecutor
+import time
+import os
 from pathlib import Path
 
 import numpy as np
 import torch
 
-from mile_amd.callbacks import save_flat_sample
+from mile_amd.sample_writer import WriterPool
 from mile_amd.kernels import KERNELS
 from mile_amd.probabilistic import resolve_target
 from mile_amd.tree import as_key, ravel_tree
@@ -49,7 +50,7 @@ def warmup_mclmc(config, rng_key, init_params, unnorm_log_posterior, n_devices: 
 
 
 def inference_loop(unnorm_log_posterior, config, rng_key, init_params, step_ids, saving_path: Path,
-                   saving_path_warmup: Path | None = None, chunk_steps: int = 500, io_workers: int = 8,
+                   saving_path_warmup: Path | None = None, chunk_steps: int = 500, io_workers: int | None = None,
                    return_samples: bool = False):
     """Same arguments and side effects as the reference's inference_loop (sampling.py:32-40).
 
@@ -76,6 +77,7 @@ def inference_loop(unnorm_log_posterior, config, rng_key, init_params, step_ids,
         raise ValueError(f'init_params has {flat0.shape[0]} chains but step_ids has {n_devices}')
 
     logger.info('> Starting Warmup sampling...')
+    t_w0 = time.time()
     warmup_state, parameters = warmup_mclmc(config=config, rng_key=warmup_key, init_params=flat0,
                                             unnorm_log_posterior=unnorm_log_posterior, n_devices=n_devices,
                                             chain_ids=chain_ids)
@@ -85,7 +87,8 @@ def inference_loop(unnorm_log_posterior, config, rng_key, init_params, step_ids,
     with open(saving_path.parent / 'warmup_params.txt', 'w') as f:      # sampling.py:92-97
         f.write(','.join(str(v) for v in eps_host) + '\n')
         f.write(','.join(str(v) for v in L_host) + '\n')
-    logger.info('> Warmup sampling completed successfully.')
+    torch.cuda.synchronize(eng.device)
+    logger.info(f'> Warmup sampling completed successfully. ({time.time() - t_w0:.2f} s)')
 
     # Sampling with the tuned parameters.  blackjax.mclmc(logdensity_fn, L, step_size): the tuned
     # preconditioner is NOT forwarded (sampling.py:291), sqrt_diag_cov stays 1.
@@ -94,8 +97,12 @@ def inference_loop(unnorm_log_posterior, config, rng_key, init_params, step_ids,
     state = warmup_state if config.use_warmup_as_init else eng.init(flat0, seed=sample_key.seed, particle_ids=chain_ids)
     logger.info(f'> Starting {config.name} Sampling...')
     kept_all = []
-    pool = ThreadPoolExecutor(max_workers=io_workers)
-    futures = []
+    t_s0 = time.time()
+    # the reference writes one zlib-compressed .npz per kept sample and chain from inside the scan; here a pool of
+    # writer SUBPROCESSES (numpy only, GPUs hidden, nothing forked from this GPU process) does it off the stepping path
+    io_workers = io_workers or max(2, min(12, (os.cpu_count() or 4) - 2))
+    pool = WriterPool(io_workers)
+    leaves = [(n, o, tuple(sh)) for n, o, sh in model.spec.leaves()]
     done = 0
     n_thin = max(int(config.n_thinning), 1)
     while done < config.n_samples:
@@ -108,14 +115,14 @@ def inference_loop(unnorm_log_posterior, config, rng_key, init_params, step_ids,
             host = samples.to('cpu', non_blocking=False).numpy()          # [K, E, d]
             if return_samples:
                 kept_all.append(torch.from_numpy(host))
-            for k, n in enumerate(idxs):
-                for e, cid in enumerate(step_ids):
-                    futures.append(pool.submit(save_flat_sample, model.spec, host[k, e], saving_path, int(cid), int(n)))
+            for e, cid in enumerate(step_ids):
+                pool.submit(leaves, np.ascontiguousarray(host[:, e]), str(saving_path), int(cid), idxs)
         done += c
-    for fut in futures:
-        fut.result()
-    pool.shutdown()
     torch.cuda.synchronize(eng.device)
+    t_s1 = time.time()
+    n_files = pool.close()
+    logger.info(f'> stepping {t_s1 - t_s0:.2f} s, waiting for sample files {time.time() - t_s1:.2f} s '
+                f'({n_files} files, {io_workers} writer processes)')
     logger.info(f'> {config.name} Sampling completed successfully.')
     with open(saving_path / 'info.pkl', 'wb') as f:                       # sampling.py:212-216
         pickle.dump(info, f)

@@ -55,15 +55,7 @@ def as_key(k) -> PRNGKey:
     raise TypeError(f'rng_key must be a mile_amd.tree.PRNGKey or an int seed, got {type(k)}')
 
 
-def get_flattened_keys(d: dict, sep: str = '.') -> list[str]:
-    """src/utils.py:50-70: dotted paths of the leaves, dict order."""
-    keys = []
-    for k, v in d.items():
-        if isinstance(v, dict):
-            keys.extend([f'{k}{sep}{kk}' for kk in get_flattened_keys(v)])
-        else:
-            keys.append(k)
-    return keys
+from mile_amd.callbacks import get_flattened_keys  # noqa: E402,F401  (pure-Python helper lives with the I/O code)
 
 
 def _get(tree: dict, dotted: str):

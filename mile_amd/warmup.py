@@ -170,14 +170,22 @@ def mclmc_find_L_and_step_size(eng, state: IntegratorState, rng_key, *, tune1_st
             keep = set(torch.linspace(0, tune3_steps - 1, fft_samples_limit).to(torch.int32).tolist())
         trace = []
         sd = sdc_cur[0] if diagonal_preconditioning else None
-        for i in range(tune3_steps):
-            z = noise_fn(10 ** 9 + i)[None] if noise_fn is not None else None
-            state, _, _ = eng.step(state, eps, L, n_steps=1, noise=z, seed=part2_key.seed, step_offset=i,
-                                   particle_ids=chain_ids, refresh=refresh, sqrt_diag_cov=sd, want_info=False,
-                                   inplace=True)
-            if keep is None or i in keep:
-                trace.append(torch.gather(state.position, 1, cols))
-        flat = torch.stack(trace, dim=1)                                   # [E, S, P]
+        state = IntegratorState(*(t.clone() for t in state))
+        chunk = max(1, min(64, (1 << 28) // max(E * d, 1)))              # <= 1 GiB of kept positions per call
+        done = 0
+        while done < tune3_steps:                                        # scan of kernel steps, all positions kept
+            c = min(chunk, tune3_steps - done)
+            z = torch.stack([noise_fn(10 ** 9 + done + i) for i in range(c)]) if noise_fn is not None else None
+            state, _, kept_pos = eng.step(state, eps, L, n_steps=c, noise=z, seed=part2_key.seed, step_offset=done,
+                                          n_thinning=1, particle_ids=chain_ids, refresh=refresh, sqrt_diag_cov=sd,
+                                          want_info=False, inplace=True)
+            sub = torch.gather(kept_pos, 2, cols[None].expand(c, -1, -1))         # [c, E, P]
+            if keep is not None:
+                sel = [i for i in range(c) if (done + i) in keep]
+                sub = sub[sel]
+            trace.append(sub)
+            done += c
+        flat = torch.cat(trace, dim=0).permute(1, 0, 2).contiguous()       # [E, S, P]
         mean_ratio = torch.empty(E, **f32)
         for e in range(E):
             ess = effective_sample_size(flat[e][None])

@@ -180,6 +180,23 @@ def test_sample_files_have_reference_layout(tmp_path):
     assert (tmp_path / 'tree').exists()
 
 
+def test_writer_pool_subprocesses_write_the_same_files(tmp_path):
+    from mile_amd import ModelSpec
+    from mile_amd.callbacks import load_samples_from_dir, save_flat_sample
+    from mile_amd.sample_writer import WriterPool
+    spec = ModelSpec(5, (16, 16, 2))
+    leaves = [(n, o, tuple(sh)) for n, o, sh in spec.leaves()]
+    flat = np.random.default_rng(0).standard_normal((3, 4, 402)).astype(np.float32)
+    pool = WriterPool(2)
+    for c in range(3):
+        pool.submit(leaves, flat[c], str(tmp_path / 'samples'), c + 5, [0, 10, 20, 30])
+    assert pool.close() == 12
+    assert np.array_equal(load_samples_from_dir(tmp_path / 'samples', spec), flat)
+    save_flat_sample(spec, flat[0, 1], tmp_path / 'ref', 5, 10)          # same bytes as the in-process writer
+    with np.load(tmp_path / 'ref' / '5' / 'sample_10.npz') as a, np.load(tmp_path / 'samples' / '5' / 'sample_10.npz') as b:
+        assert a.files == b.files and all(np.array_equal(a[k], b[k]) for k in a.files)
+
+
 def test_tabular_loader_normalises_and_splits(tmp_path):
     from mile_amd.config import DataConfig
     from mile_amd.dataset import TabularLoader
