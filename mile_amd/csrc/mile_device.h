@@ -74,8 +74,20 @@ __device__ __forceinline__ float act_bwd(int act, float h) {
   return h * (1.0f - h);
 }
 
+// Sum over the 64 lanes of a wave, result in every lane.  DPP only (no LDS traffic: __shfl_xor
+// compiles to ds_bpermute_b32): butterfly inside each 16-lane row, then row_bcast:15 / :31 carry
+// the row sums up to lane 63, which is read back through an SGPR.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+  return v + __int_as_float(t);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xF>(v);   // row_half_mirror
+  v = dpp_add<0x140, 0xF>(v);   // row_mirror: every lane now holds its row's sum
+  v = dpp_add<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }

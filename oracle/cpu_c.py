@@ -1,0 +1,62 @@
+"""ctypes access to oracle/libcpu_mclmc.so (the C/OpenMP restatement) -- test and baseline
+infrastructure only, like the rest of oracle/."""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+LIB = HERE / 'libcpu_mclmc.so'
+
+
+class CpuSpec(C.Structure):
+    _fields_ = [('n_layers', C.c_int), ('in_features', C.c_int), ('widths', C.c_int * 16), ('w_off', C.c_int * 16),
+                ('b_off', C.c_int * 16), ('d', C.c_int), ('prior_loc', C.c_float), ('prior_scale', C.c_float)]
+
+
+def load(build: bool = True):
+    if build and (not LIB.exists() or LIB.stat().st_mtime < (HERE / 'cpu_mclmc.c').stat().st_mtime):
+        subprocess.run(['make', '-C', str(HERE)], check=True, capture_output=True)
+    lib = C.CDLL(str(LIB))
+    lib.cpu_threads.restype = C.c_int
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class CpuPort:
+    """ReLU / regression / Normal-prior FCN only (BASELINE configs B1, B2)."""
+
+    def __init__(self, spec, X, y):
+        assert spec.activation == 'relu' and spec.task == 'regr' and spec.prior == 'Normal'
+        self.lib = load()
+        self.cs = CpuSpec()
+        w = (C.c_int * len(spec.hidden_structure))(*spec.hidden_structure)
+        self.lib.cpu_spec_init(C.byref(self.cs), spec.in_features, len(spec.hidden_structure), w,
+                               C.c_float(spec.prior_loc), C.c_float(spec.prior_scale))
+        assert self.cs.d == spec.n_params
+        self.X = np.ascontiguousarray(X, np.float32)
+        self.y = np.ascontiguousarray(y, np.float32)
+        self.threads = int(self.lib.cpu_threads())
+
+    def logpost_grad(self, theta):
+        theta = np.ascontiguousarray(theta, np.float32)
+        E = theta.shape[0]
+        logp, grad = np.empty(E, np.float32), np.empty_like(theta)
+        self.lib.cpu_logpost_grad(C.byref(self.cs), _p(theta), E, _p(self.X), _p(self.y), len(self.y), _p(logp), _p(grad))
+        return logp, grad
+
+    def steps(self, x, u, logp, g, eps, L, noise, want_info=False):
+        """In place on x, u, logp, g (fp32 contiguous).  noise [T, 2, E, d]."""
+        T, E = noise.shape[0], x.shape[0]
+        info = np.empty((T, E, 3), np.float32) if want_info else None
+        self.lib.cpu_mclmc_steps(C.byref(self.cs), _p(x), _p(u), _p(logp), _p(g), E,
+                                 _p(np.ascontiguousarray(eps, np.float32)), _p(np.ascontiguousarray(L, np.float32)),
+                                 _p(np.ascontiguousarray(noise, np.float32)), T, _p(self.X), _p(self.y), len(self.y),
+                                 _p(info) if info is not None else None)
+        return info
