@@ -183,6 +183,13 @@ int32_t mile_step(mile_sampler *s, mile_state *state, const mile_step_args *args
  * Advances `state` in place; supported for d <= 16384 (returns MILE_ERR_INVALID beyond). */
 int32_t mile_tune(mile_sampler *s, mile_state *state, const mile_tune_args *args, void *stream);
 
+/* Replaces: the per-sample forward pass + log_prob of the evaluation path, i.e. predict_from_samples /
+ * pointwise_lppd (src/inference/evaluation.py:16-43, src/inference/metrics.py:247-294).
+ * theta [S, d] (S posterior samples, any chains), X [N, F] and y [N] (fp32 or int32 labels) are device
+ * pointers of a TEST set (independent of mile_set_data); out [S, N] = log p(y_n | x_n, theta_s). */
+int32_t mile_pointwise_loglik(mile_sampler *s, const float *theta, int32_t S, const float *X, const void *y,
+                              int64_t N, float *out, void *stream);
+
 /* Counter-RNG words/normals exactly as the step kernels draw them (test hook). out [E, d]. */
 int32_t mile_debug_noise(mile_sampler *s, uint64_t seed, const int32_t *particle_ids, int32_t E,
                          int64_t step, int32_t stage, float *out, void *stream);

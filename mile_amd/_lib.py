@@ -86,6 +86,8 @@ SIGNATURES = {
     'mile_init': (C.c_int32, [C.c_void_p, C.POINTER(StateC), C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     'mile_step': (C.c_int32, [C.c_void_p, C.POINTER(StateC), C.POINTER(StepArgsC), C.c_void_p]),
     'mile_tune': (C.c_int32, [C.c_void_p, C.POINTER(StateC), C.POINTER(TuneArgsC), C.c_void_p]),
+    'mile_pointwise_loglik': (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                          C.c_void_p, C.c_void_p]),
     'mile_debug_noise': (C.c_int32, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int32, C.c_int64, C.c_int32,
                                      C.c_void_p, C.c_void_p]),
     'mile_grad_launch_info': (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),

@@ -13,6 +13,7 @@
 #include "mile_device.h"
 #include "mile_grad_generic.h"
 #include "mile_grad_w64.h"
+#include "mile_predict.h"
 #include "mile_update.h"
 
 static thread_local std::string g_err;
@@ -38,6 +39,7 @@ struct mile_sampler {
   // workspace
   int E_cap = 0, S_cap = 0;
   float *slabs = nullptr, *llpart = nullptr, *dK = nullptr, *lold = nullptr;
+  float *ev_X = nullptr, *ev_Xp = nullptr; void *ev_y = nullptr; int ev_cap = 0;   // evaluation (test) set staging
   float *alt_x = nullptr, *alt_u = nullptr, *alt_g = nullptr, *alt_logp = nullptr;   // ping-pong state of mile_tune
   int grad_kernel = MILE_GRAD_AUTO;
   // timing of grad launches
@@ -171,6 +173,9 @@ static void free_ws(mile_sampler *s) {
 
 int32_t mile_destroy(mile_sampler *s) {
   if (!s) return MILE_OK;
+  if (s->ev_X) (void)hipFree(s->ev_X);
+  if (s->ev_Xp) (void)hipFree(s->ev_Xp);
+  if (s->ev_y) (void)hipFree(s->ev_y);
   free_data(s);
   free_ws(s);
   for (auto ev : s->ev) (void)hipEventDestroy(ev);
@@ -350,6 +355,66 @@ static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t s
     HIP_TRY(hipGetLastError());
   }
   if (s->timing) HIP_TRY(hipEventRecord(e1, st));
+  return MILE_OK;
+}
+
+template <int NH, int FQ>
+static hipError_t launch_fwd_w64(const PredParams &pp, int S, hipStream_t st) {
+  using LY = W64Layout<NH, FQ>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)k_fwd_w64<NH, FQ>, hipFuncAttributeMaxDynamicSharedMemorySize, LY::BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  k_fwd_w64<NH, FQ><<<dim3(pp.SB, S), 256, LY::BYTES, st>>>(pp);
+  return hipGetLastError();
+}
+
+extern "C" int32_t mile_pointwise_loglik(mile_sampler *s, const float *theta, int32_t S, const float *X, const void *y,
+                                         int64_t N, float *out, void *stream) {
+  if (!s || !theta || !X || !y || !out || S < 1) return fail(MILE_ERR_INVALID, "mile_pointwise_loglik: bad argument");
+  if (N < 1 || N > 0x3fffffff) return fail(MILE_ERR_INVALID, "mile_pointwise_loglik: N out of range");
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipSetDevice(s->device));
+  const int F = s->spec.in_features, Npad = ((int)N + 31) / 32 * 32, Fp = (F + 7) / 8 * 8;
+  if (Npad > s->ev_cap) {   // evaluation is off the stepping path: (re)allocate its staging here
+    if (s->ev_X) (void)hipFree(s->ev_X);
+    if (s->ev_Xp) (void)hipFree(s->ev_Xp);
+    if (s->ev_y) (void)hipFree(s->ev_y);
+    s->ev_X = s->ev_Xp = nullptr; s->ev_y = nullptr; s->ev_cap = 0;
+    HIP_TRY(hipMalloc(&s->ev_X, (size_t)Npad * F * 4));
+    HIP_TRY(hipMalloc(&s->ev_Xp, (size_t)Npad * Fp * 4));
+    HIP_TRY(hipMalloc(&s->ev_y, (size_t)Npad * 4));
+    s->ev_cap = Npad;
+  }
+  HIP_TRY(hipMemcpyAsync(s->ev_X, X, (size_t)N * F * 4, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemsetAsync(s->ev_y, 0, (size_t)Npad * 4, st));
+  HIP_TRY(hipMemcpyAsync(s->ev_y, y, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
+  const long long tot = (long long)Npad * Fp;
+  k_pad_x<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(s->ev_X, s->ev_Xp, (int)N, Npad, F, Fp);
+  PredParams pp;
+  pp.spec = s->ds; pp.theta = theta; pp.X = s->ev_X; pp.Xp = s->ev_Xp; pp.y = s->ev_y; pp.out = out;
+  pp.N = (int)N; pp.Npad = Npad; pp.Fp = Fp; pp.R = generic_R(s->ds);
+  const int kernel = resolved_kernel(s);
+  if (kernel == MILE_GRAD_MFMA_W64) {
+    const int NB = Npad / 32;
+    pp.SB = std::max(1, std::min(std::max(1, (2 * s->n_cu) / S), std::max(1, NB / 4)));
+    const int nh = s->spec.n_layers - 1, fq = Fp / 8;
+    hipError_t e = hipErrorInvalidValue;
+    if (nh == 1 && fq == 1) e = launch_fwd_w64<1, 1>(pp, S, st);
+    else if (nh == 2 && fq == 1) e = launch_fwd_w64<2, 1>(pp, S, st);
+    else if (nh == 3 && fq == 1) e = launch_fwd_w64<3, 1>(pp, S, st);
+    else if (nh == 1 && fq == 2) e = launch_fwd_w64<1, 2>(pp, S, st);
+    else if (nh == 2 && fq == 2) e = launch_fwd_w64<2, 2>(pp, S, st);
+    else if (nh == 3 && fq == 2) e = launch_fwd_w64<3, 2>(pp, S, st);
+    HIP_TRY(e);
+  } else {
+    pp.SB = std::max(1, std::min(std::max(1, (4 * s->n_cu) / S), std::max(1, (int)N / 64)));
+    const size_t lds = ((size_t)pp.R * s->ds.act_stride + 16) * 4;
+    k_fwd_generic<<<dim3(pp.SB, S), 256, lds, st>>>(pp);
+    HIP_TRY(hipGetLastError());
+  }
   return MILE_OK;
 }
 

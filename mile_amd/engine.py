@@ -285,6 +285,23 @@ class Engine:
             _lib.check(self.lib.mile_tune(self._h, C.byref(sc), C.byref(a), self._stream()), self.lib)
         return MCLMCInfo(info[..., 0], info[..., 1], info[..., 2]) if info is not None else None
 
+    def pointwise_loglik(self, theta, X, y) -> torch.Tensor:
+        """log p(y_n | x_n, theta_s) for every sample and test row: theta [..., d] -> [..., N]
+        (pointwise_lppd's input, src/inference/metrics.py:247-294), computed by the HIP forward kernels."""
+        theta = _f32(theta, self.device, name='theta')
+        lead = theta.shape[:-1]
+        th = theta.reshape(-1, self.d).contiguous()
+        X = _f32(X, self.device, name='X')
+        y = torch.as_tensor(y, device=self.device)
+        y = (y.to(torch.float32) if self.spec.task == 'regr' else y.to(torch.int32)).contiguous()
+        if X.ndim != 2 or X.shape[1] != self.spec.in_features or y.shape != (X.shape[0],):
+            raise ValueError('X must be [N, F] and y [N]')
+        out = torch.empty((th.shape[0], X.shape[0]), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mile_pointwise_loglik(self._h, _ptr(th), th.shape[0], _ptr(X), _ptr(y), X.shape[0],
+                                                      _ptr(out), self._stream()), self.lib)
+        return out.reshape(*lead, X.shape[0])
+
     @property
     def supports_device_tuner(self) -> bool:
         return 4 <= self.d <= 16384
