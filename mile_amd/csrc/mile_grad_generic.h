@@ -18,6 +18,7 @@ struct GradParams {
   float *slabs;         // [E, S, d]
   float *llpart;        // [E, S]
   int32_t N, Npad, Fp, S, R;
+  int32_t dp;           // slab row stride: d rounded up to a multiple of 4 floats (128-bit stores)
   int32_t dbg;          // debug knobs (MILE_DEBUG env): bit0 skip row blocks, bit1 skip staging, bit2 skip reduction
 };
 
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256) void k_grad_generic(const GradParams p) {
   const int e = blockIdx.y, s = blockIdx.x;
   const int d = sp.d, nl = sp.n_layers, as = sp.act_stride, mw = sp.max_width, R = p.R;
   const float *th = p.theta + (size_t)e * d;
-  float *slab = p.slabs + ((size_t)e * p.S + s) * d;
+  float *slab = p.slabs + ((size_t)e * p.S + s) * p.dp;
   float *act = lds;
   float *dzc = act + R * as;
   float *dzn = dzc + R * mw;

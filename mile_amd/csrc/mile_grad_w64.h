@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p) {
   const int e = blockIdx.y, s = blockIdx.x;
   const int d = sp.d, F = sp.in_features;
   const float *th = p.theta + (size_t)e * d;
-  float *slab = p.slabs + ((size_t)e * p.S + s) * d;
+  float *slab = p.slabs + ((size_t)e * p.S + s) * p.dp;
 
   float *WIMG = lds + LY::WIMG, *W1IMG = lds + LY::W1IMG, *BIAS = lds + LY::BIAS;
   float *WO = lds + LY::WO, *BO = lds + LY::BO;
@@ -340,10 +340,21 @@ __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p) {
   for (int l = 0; l < NH - 1; ++l) {
     float *out = slab + sp.w_off[l + 1];
     const float *R0 = RED + l * 4 * 64 * W64_RS;
+    if ((sp.w_off[l + 1] & 3) == 0) {     // 128-bit path: the slab row is 16-byte aligned (dp % 4 == 0)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int q = tid + 256 * k;        // float4 index: row q >> 4, columns 4 (q & 15) ..
+        const int o = (q >> 4) * W64_RS + 4 * (q & 15);
+        const f32x4 v = (*(const f32x4 *)(R0 + o) + *(const f32x4 *)(R0 + 64 * W64_RS + o)) +
+                        (*(const f32x4 *)(R0 + 2 * 64 * W64_RS + o) + *(const f32x4 *)(R0 + 3 * 64 * W64_RS + o));
+        *(f32x4 *)(out + 4 * q) = v;
+      }
+    } else {
 #pragma unroll 4
-    for (int idx = tid; idx < 4096; idx += 256) {
-      const int o = (idx >> 6) * W64_RS + (idx & 63);
-      out[idx] = (R0[o] + R0[64 * W64_RS + o]) + (R0[2 * 64 * W64_RS + o] + R0[3 * 64 * W64_RS + o]);
+      for (int idx = tid; idx < 4096; idx += 256) {
+        const int o = (idx >> 6) * W64_RS + (idx & 63);
+        out[idx] = (R0[o] + R0[64 * W64_RS + o]) + (R0[2 * 64 * W64_RS + o] + R0[3 * 64 * W64_RS + o]);
+      }
     }
   }
   __syncthreads();

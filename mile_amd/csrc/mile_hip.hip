@@ -231,7 +231,7 @@ int32_t mile_reserve(mile_sampler *s, int32_t E) {
                          w64_supported(s->spec) ? choose_S(s, E, MILE_GRAD_MFMA_W64) : 1);
   if (E <= s->E_cap && S <= s->S_cap) return MILE_OK;
   free_ws(s);
-  HIP_TRY(hipMalloc(&s->slabs, (size_t)E * S * s->ds.d * 4));
+  HIP_TRY(hipMalloc(&s->slabs, (size_t)E * S * ((s->ds.d + 3) / 4 * 4) * 4));
   HIP_TRY(hipMalloc(&s->llpart, (size_t)E * S * 4));
   HIP_TRY(hipMalloc(&s->dK, (size_t)E * 4));
   HIP_TRY(hipMalloc(&s->lold, (size_t)E * 4));
@@ -324,7 +324,7 @@ static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t s
   gp.theta = theta;
   gp.X = s->X; gp.Xp = s->Xp; gp.y = s->y;
   gp.slabs = s->slabs; gp.llpart = s->llpart;
-  gp.N = s->N; gp.Npad = s->Npad; gp.Fp = s->Fp; gp.S = S; gp.R = generic_R(s->ds);
+  gp.N = s->N; gp.Npad = s->Npad; gp.Fp = s->Fp; gp.S = S; gp.R = generic_R(s->ds); gp.dp = (s->ds.d + 3) / 4 * 4;
   { const char *dv = getenv("MILE_DEBUG"); gp.dbg = dv ? atoi(dv) : 0; }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (s->timing) {
@@ -475,7 +475,7 @@ int32_t mile_logpost_grad(mile_sampler *s, const float *theta, int32_t E, float 
   int rc = launch_grad(s, theta, E, st);
   if (rc) return rc;
   const int S = choose_S(s, E, resolved_kernel(s));
-  k_finalize<<<E, AUX_NT, 0, st>>>(s->ds.d, S, s->ds.prior, s->ds.prior_loc, s->ds.prior_scale, theta,
+  k_finalize<<<E, AUX_NT, 0, st>>>(s->ds.d, (s->ds.d + 3) / 4 * 4, S, s->ds.prior, s->ds.prior_loc, s->ds.prior_scale, theta,
                                    s->slabs, s->llpart, grad, logp);
   HIP_TRY(hipGetLastError());
   return MILE_OK;
@@ -514,7 +514,7 @@ int32_t mile_step(mile_sampler *s, mile_state *state, const mile_step_args *a, v
   if (E > s->E_cap || S > s->S_cap) return fail(MILE_ERR_STATE, "workspace too small: call mile_reserve(E) first");
 
   UpdParams up{};
-  up.d = d; up.E = E; up.S = S;
+  up.d = d; up.E = E; up.S = S; up.dp = (d + 3) / 4 * 4;
   up.prior = s->ds.prior; up.prior_loc = s->ds.prior_loc; up.prior_scale = s->ds.prior_scale;
   up.x = state->position; up.u = state->momentum; up.g = state->logdensity_grad; up.logp = state->logdensity;
   up.slabs = s->slabs; up.llpart = s->llpart;
@@ -593,7 +593,7 @@ int32_t mile_tune(mile_sampler *s, mile_state *state, const mile_tune_args *a, v
   const Buf A{state->position, state->momentum, state->logdensity_grad, state->logdensity};
   const Buf B{s->alt_x, s->alt_u, s->alt_g, s->alt_logp};
   UpdParams up{};
-  up.d = d; up.E = E; up.S = S;
+  up.d = d; up.E = E; up.S = S; up.dp = (d + 3) / 4 * 4;
   up.prior = s->ds.prior; up.prior_loc = s->ds.prior_loc; up.prior_scale = s->ds.prior_scale;
   up.slabs = s->slabs; up.llpart = s->llpart;
   up.eps = a->step_size; up.L = a->L; up.sdc = a->sqrt_diag_cov;

@@ -29,6 +29,7 @@ enum : int32_t {
 
 struct UpdParams {
   int32_t d, E, S, flags;
+  int32_t dp;                    // slab row stride (floats)
   int32_t prior;
   float prior_loc, prior_scale;
   float *x, *u, *g, *logp;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(UPD_NT) void k_update(const UpdParams p) {
   const bool from_slabs = p.flags & UPD_FROM_SLABS;
   const bool useA = p.flags & UPD_OA, useB = p.flags & UPD_OB;
   const uint32_t pid = p.pids ? (uint32_t)p.pids[e] : (uint32_t)e;
-  const float *sl = p.slabs + (size_t)e * p.S * d;
+  const float *sl = p.slabs + (size_t)e * p.S * p.dp;
   constexpr int NK = CACHED ? UPD_QMAX : 1;
   f32x4 cx[NK], cu[NK], cg[NK], ca[NK], cb[NK];
 
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(UPD_NT) void k_update(const UpdParams p) {
         const float xi = p.x[base + i];
         if (from_slabs) {
           gi = 0.0f;
-          for (int s = 0; s < p.S; ++s) gi += sl[(size_t)s * d + i];
+          for (int s = 0; s < p.S; ++s) gi += sl[(size_t)s * p.dp + i];
           const float t = (xi - p.prior_loc) / p.prior_scale;
           if (p.prior == MILE_PRIOR_NORMAL) {
             gi -= t / p.prior_scale;
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
   const bool useA = p.flags & UPD_OA, useB = p.flags & UPD_OB;
   const bool explA = useA && p.zA, explB = useB && p.zB;
   const uint32_t pid = p.pids ? (uint32_t)p.pids[e] : (uint32_t)e;
-  const float *sl = p.slabs + (size_t)e * p.S * d;
+  const float *sl = p.slabs + (size_t)e * p.S * p.dp;
   const float *xin = p.x_in ? p.x_in : p.x, *uin = p.u_in ? p.u_in : p.u, *gin = p.g_in ? p.g_in : p.g;
   const bool tune = p.flags & UPD_TUNE;
   const float ips = 1.0f / p.prior_scale;
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
     cu[k] = ld4<AL>(uin + o);
     if (from_slabs) {
       f32x4 g = ld4<AL>(sl + (o - base));
-      for (int s = 1; s < p.S; ++s) g += ld4<AL>(sl + (size_t)s * d + (o - base));
+      for (int s = 1; s < p.S; ++s) g += ld4<AL>(sl + (size_t)s * p.dp + (o - base));
       cg[k] = g;
     } else {
       cg[k] = ld4<AL>(gin + o);
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
   if (ntail) {
     const size_t tc = has_tail ? to : base;
     tx = xin[tc]; tu = uin[tc];
-    if (from_slabs) { tg = 0.0f; for (int s = 0; s < p.S; ++s) tg += sl[(size_t)s * d + (tc - base)]; }
+    if (from_slabs) { tg = 0.0f; for (int s = 0; s < p.S; ++s) tg += sl[(size_t)s * p.dp + (tc - base)]; }
     else tg = gin[tc];
     if (SDC) tsd = p.sdc[tc];
     if (explA) ta = p.zA[tc];
@@ -585,17 +586,17 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
 
 #define AUX_NT 256
 // g = sum_s slab + grad log prior;  logp = sum_s llpart + log prior.   (mile_logpost_grad)
-__global__ __launch_bounds__(AUX_NT) void k_finalize(int d, int S, int prior, float loc, float scale,
+__global__ __launch_bounds__(AUX_NT) void k_finalize(int d, int dp, int S, int prior, float loc, float scale,
                                                      const float *theta, const float *slabs,
                                                      const float *llpart, float *grad, float *logp) {
   __shared__ float red[AUX_NT / 64];
   const int tid = threadIdx.x, e = blockIdx.x;
   const size_t base = (size_t)e * d;
-  const float *sl = slabs + (size_t)e * S * d;
+  const float *sl = slabs + (size_t)e * S * dp;
   float pv = 0.0f;
   for (int i = tid; i < d; i += AUX_NT) {
     float gi = 0.0f;
-    for (int s = 0; s < S; ++s) gi += sl[(size_t)s * d + i];
+    for (int s = 0; s < S; ++s) gi += sl[(size_t)s * dp + i];
     const float t = (theta[base + i] - loc) / scale;
     if (prior == MILE_PRIOR_NORMAL) { gi -= t / scale; pv += -0.5f * t * t; }
     else { gi -= (t > 0.0f ? 1.0f : (t < 0.0f ? -1.0f : 0.0f)) / scale; pv += -fabsf(t); }
