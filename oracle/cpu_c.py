@@ -17,6 +17,28 @@ class CpuSpec(C.Structure):
                 ('b_off', C.c_int * 16), ('d', C.c_int), ('prior_loc', C.c_float), ('prior_scale', C.c_float)]
 
 
+def effective_cpus() -> int:
+    """CPUs this process may really use: affinity mask and cgroup quota (a container can see 128 CPUs and own 16)."""
+    import math
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, math.ceil(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                    n = min(n, max(1, math.ceil(q / per)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def load(build: bool = True):
     if build and (not LIB.exists() or LIB.stat().st_mtime < (HERE / 'cpu_mclmc.c').stat().st_mtime):
         subprocess.run(['make', '-C', str(HERE)], check=True, capture_output=True)
@@ -42,6 +64,7 @@ class CpuPort:
         assert self.cs.d == spec.n_params
         self.X = np.ascontiguousarray(X, np.float32)
         self.y = np.ascontiguousarray(y, np.float32)
+        self.lib.cpu_set_threads(effective_cpus())
         self.threads = int(self.lib.cpu_threads())
 
     def logpost_grad(self, theta):

@@ -25,6 +25,14 @@ typedef struct {
   float prior_loc, prior_scale;
 } cpu_spec;
 
+void cpu_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int cpu_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools_pmc.sh <outdir-under-gpurun_out> <extra bench args...>
 # Separate --pmc passes (never combined with trace domains other than kernel-trace).
-OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift   # usage (on the GPU box): tools/pmc_*.sh <outdir> [bench args]
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA"

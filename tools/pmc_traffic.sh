@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic counters, each in its own --pmc pass (TCC slots), kernel-trace only.
-OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift   # usage (on the GPU box): tools/pmc_*.sh <outdir> [bench args]
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=1
