@@ -25,6 +25,8 @@
 // Work per 32-row block and wave: 392 v_mfma_f32_32x32x2_f32 (8 + 2*64 forward,
 // 4*64 backward) = 1.606 MFLOP of the 1.638 MFLOP the algorithm needs for 32 rows.
 #pragma once
+#include <type_traits>
+
 #include "mile_device.h"
 #include "mile_grad_generic.h"
 
@@ -65,7 +67,8 @@ struct W64Layout {
   static constexpr int XT = IMG + 32 * W64_RS;                    // [32][FP]
   static constexpr int DOUT = XT + 32 * FP;                       // [32][2]
   static constexpr int WAVE_SZ = DOUT + 64;
-  static constexpr int MAIN = WAVE0 + 4 * WAVE_SZ;
+  static constexpr int XB = WAVE0 + 4 * WAVE_SZ;                  // [2 pairs][2][2][16][64] tile exchange (COOP)
+  static constexpr int MAIN = XB + 2 * 4 * 1024;
   static constexpr int RED = NW * 4 * 64 * W64_RS;                // end-of-kernel reduction alias
   static constexpr int TOTAL = (MAIN > RED ? MAIN : RED);
   static constexpr int BYTES = TOTAL * 4;
@@ -132,188 +135,66 @@ __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p) {
   const int b0 = (int)(((long long)s * NB) / p.S);
   const int b1 = (p.dbg & 1) ? b0 : (int)(((long long)(s + 1) * NB) / p.S);
 
-  for (int blk = b0 + wave; blk < b1; blk += 4) {
-    const int row0 = blk * 32;
-    // ---- X tile: lane (j,h) holds features 8q+4h+(0..3) of row j ------------------
-    f32x4 xv[FQ];
+  // Block body: mile_grad_w64_block.inc.  COOP = false: this wave does the whole block.
+  // COOP = true: a PAIR of waves shares the block -- wave w of the pair computes output half w of every
+  // GEMM (32 of the 64 MFMAs), the two exchange their activation / dZ tiles through LDS after each layer,
+  // and each accumulates only its half of dW, db (and wave 0 the head), so a leftover block costs about
+  // half a round instead of a whole one.  Everything else is the same code.
+  float *XB = lds + LY::XB + (wave >> 1) * 4 * 1024;   // pair's tile exchange: [2 halves][2 tiles][16][64]
+  auto exchange = [&](f32x16(&T)[2], const int w, const int xid) {   // w is a compile-time constant at every call
+    float *xb = XB + (xid & 1) * 2048;
+    if (w == 0) {
 #pragma unroll
-    for (int q = 0; q < FQ; ++q) {
-      xv[q] = *(const f32x4 *)(p.Xp + (size_t)(row0 + j) * FP + 8 * q + 4 * h);
-      *(f32x4 *)(xt + j * FP + 8 * q + 4 * h) = xv[q];
+      for (int r = 0; r < 16; ++r) xb[r * 64 + lane] = T[0][r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xb[1024 + r * 64 + lane] = T[1][r];
     }
-    f32x16 H[NH][2];
-    // ---- layer 0: Z1^T = W1^T . X^T ----------------------------------------------
+    __syncthreads();
+    if (w == 0) {
 #pragma unroll
-    for (int ob = 0; ob < 2; ++ob) {
-      f32x16 acc;
+      for (int r = 0; r < 16; ++r) T[1][r] = xb[1024 + r * 64 + lane];
+    } else {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 bv = *(const f32x4 *)(BIAS + 32 * ob + 8 * g + 4 * h);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) acc[4 * g + m] = bv[m];
-      }
-#pragma unroll
-      for (int q = 0; q < FQ; ++q)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const float a = W1IMG[(8 * q + 4 * h + m) * W64_RS + 32 * ob + j];
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xv[q][m], acc, 0, 0, 0);
-        }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) H[0][ob][r] = fmaxf(acc[r], 0.0f);
+      for (int r = 0; r < 16; ++r) T[0][r] = xb[r * 64 + lane];
     }
-    // ---- hidden layers ------------------------------------------------------------
-#pragma unroll
-    for (int l = 1; l < NH; ++l) {
-      const float *Wl = WIMG + (l - 1) * 64 * W64_RS;
-#pragma unroll
-      for (int ob = 0; ob < 2; ++ob) {
-        f32x16 acc;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 bv = *(const f32x4 *)(BIAS + l * 64 + 32 * ob + 8 * g + 4 * h);
-#pragma unroll
-          for (int m = 0; m < 4; ++m) acc[4 * g + m] = bv[m];
-        }
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int t = 0; t < 16; ++t) {
-            const float a = Wl[(32 * kb + tfeat(t, h)) * W64_RS + 32 * ob + j];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, H[l - 1][kb][t], acc, 0, 0, 0);
-          }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) H[l][ob][r] = fmaxf(acc[r], 0.0f);
-      }
+  };
+  const int nblk = b1 - b0, nfull = nblk >> 2, rem = nblk & 3;
+  for (int r = 0; r < nfull; ++r) {
+    const int row0 = (b0 + 4 * r + wave) * 32;
+#define W64_COOP 0
+#define W64_W 0
+#include "mile_grad_w64_block.inc"
+#undef W64_COOP
+#undef W64_W
+  }
+  if (rem == 3) {               // three leftovers: one more independent round
+    if (wave < 3) {
+      const int row0 = (b0 + 4 * nfull + wave) * 32;
+#define W64_COOP 0
+#define W64_W 0
+#include "mile_grad_w64_block.inc"
+#undef W64_COOP
+#undef W64_W
     }
-    // ---- output layer (64 -> 2) on the VALU + Gaussian head ----------------------
-    float p0 = 0.0f, p1 = 0.0f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 w0 = *(const f32x4 *)(WO + 32 * kb + 8 * g + 4 * h);
-        const f32x4 w1 = *(const f32x4 *)(WO + 64 + 32 * kb + 8 * g + 4 * h);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          p0 = fmaf(w0[m], H[NH - 1][kb][4 * g + m], p0);
-          p1 = fmaf(w1[m], H[NH - 1][kb][4 * g + m], p1);
-        }
+  } else if (rem) {             // one or two leftovers: wave pairs share them
+    if ((wave >> 1) < rem) {
+      const int row0 = (b0 + 4 * nfull + (wave >> 1)) * 32;
+      if (wave & 1) {
+#define W64_COOP 1
+#define W64_W 1
+#include "mile_grad_w64_block.inc"
+#undef W64_COOP
+#undef W64_W
+      } else {
+#define W64_COOP 1
+#define W64_W 0
+#include "mile_grad_w64_block.inc"
+#undef W64_COOP
+#undef W64_W
       }
-    p0 += __shfl_xor(p0, 32);
-    p1 += __shfl_xor(p1, 32);
-    const float mu = p0 + BO[0], sr = p1 + BO[1];
-    float dmu, ds;
-    float ll = row_loss_regr(mu, sr, ((const float *)p.y)[row0 + j], dmu, ds);
-    if (row0 + j >= p.N) { ll = 0.0f; dmu = 0.0f; ds = 0.0f; }
-    if (h == 0) {
-      llacc += ll;
-      boacc[0] += dmu;
-      boacc[1] += ds;
-      *(f32x2 *)(dout_l + 2 * j) = f32x2{dmu, ds};
-    }
-    // ---- dZ of the last hidden layer ----------------------------------------------
-    f32x16 dZ[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 w0 = *(const f32x4 *)(WO + 32 * kb + 8 * g + 4 * h);
-        const f32x4 w1 = *(const f32x4 *)(WO + 64 + 32 * kb + 8 * g + 4 * h);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const float dh = fmaf(w0[m], dmu, w1[m] * ds);
-          dZ[kb][4 * g + m] = H[NH - 1][kb][4 * g + m] > 0.0f ? dh : 0.0f;
-        }
-      }
-    // ---- dW_out[f][c] += sum_rows H_last[f][row] dout[row][c]  (row-contracting, VALU)
-    wave_lds_sync();
-    write_image(img, H[NH - 1], j, h);
-    wave_lds_sync();
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int ss = 0; ss < 16; ++ss) {
-        const int n = nrow(ss, h);
-        const float v = img[n * W64_RS + 32 * kb + j];
-        const f32x2 dd = *(const f32x2 *)(dout_l + 2 * n);
-        woacc[kb][0] = fmaf(v, dd[0], woacc[kb][0]);
-        woacc[kb][1] = fmaf(v, dd[1], woacc[kb][1]);
-      }
-    // ---- hidden layers, backward ---------------------------------------------------
-#pragma unroll
-    for (int l = NH - 1; l >= 1; --l) {
-      const float *Wl = WIMG + (l - 1) * 64 * W64_RS;
-      wave_lds_sync();
-      write_image(img, dZ, j, h);
-      wave_lds_sync();
-      f32x16 afr[2];
-#pragma unroll
-      for (int ob = 0; ob < 2; ++ob) {
-        float bs = 0.0f;
-#pragma unroll
-        for (int ss = 0; ss < 16; ++ss) {
-          afr[ob][ss] = img[nrow(ss, h) * W64_RS + 32 * ob + j];
-          bs += afr[ob][ss];
-        }
-        bacc[l][ob] += bs;
-      }
-      wave_lds_sync();
-      write_image(img, H[l - 1], j, h);
-      wave_lds_sync();
-      // dW_l^T[out][in] += dZ_l^T[out][rows] . H_{l-1}[rows][in]
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-        for (int ss = 0; ss < 16; ++ss) {
-          const float b = img[nrow(ss, h) * W64_RS + 32 * ib + j];
-#pragma unroll
-          for (int ob = 0; ob < 2; ++ob)
-            dWacc[l - 1][ob][ib] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[ob][ss], b, dWacc[l - 1][ob][ib], 0, 0, 0);
-        }
-      // dH_{l-1}^T[in][row] = W_l[in][out] . dZ_l^T[out][row]
-      f32x16 dHn[2];
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib) {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 a4 = *(const f32x4 *)(Wl + (32 * ib + j) * W64_RS + 32 * kb + 8 * g + 4 * h);
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[m], dZ[kb][4 * g + m], acc, 0, 0, 0);
-          }
-        dHn[ib] = acc;
-      }
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dZ[ib][r] = H[l - 1][ib][r] > 0.0f ? dHn[ib][r] : 0.0f;
-    }
-    // ---- first layer: db_0, dW_0[c][out] += sum_rows X[row][c] dZ_0[out][row] (VALU) -
-    wave_lds_sync();
-    write_image(img, dZ, j, h);
-    wave_lds_sync();
-#pragma unroll
-    for (int ob = 0; ob < 2; ++ob) {
-      float bs = 0.0f;
-#pragma unroll
-      for (int ss = 0; ss < 16; ++ss) {
-        const int n = nrow(ss, h);
-        const float v = img[n * W64_RS + 32 * ob + j];
-        bs += v;
-#pragma unroll
-        for (int q4 = 0; q4 < FP / 4; ++q4) {
-          const f32x4 xr = *(const f32x4 *)(xt + n * FP + 4 * q4);
-#pragma unroll
-          for (int m = 0; m < 4; ++m) w1acc[ob][4 * q4 + m] = fmaf(v, xr[m], w1acc[ob][4 * q4 + m]);
-        }
-      }
-      bacc[0][ob] += bs;
+    } else {
+      for (int k = 0; k < 2 * NH - 1; ++k) __syncthreads();   // the other pair's exchange barriers
     }
   }
 
