@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, 1) void k_fwd_w64(const PredParams p) {
         for (int m = 0; m < 4; ++m)
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W1IMG[(8 * q + 4 * h + m) * W64_RS + 32 * ob + j], xv[q][m], acc, 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) H[0][ob][r] = fmaxf(acc[r], 0.0f);
+      for (int r = 0; r < 16; ++r) H[0][ob][r] = relu1(acc[r]);
     }
 #pragma unroll
     for (int l = 1; l < NH; ++l) {
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, 1) void k_fwd_w64(const PredParams p) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Wl[(32 * kb + tfeat(t, h)) * W64_RS + 32 * ob + j],
                                                       H[(l - 1) & 1][kb][t], acc, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) H[l & 1][ob][r] = fmaxf(acc[r], 0.0f);
+        for (int r = 0; r < 16; ++r) H[l & 1][ob][r] = relu1(acc[r]);
       }
     }
     float p0 = 0.0f, p1 = 0.0f;
