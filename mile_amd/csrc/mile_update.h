@@ -443,7 +443,9 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
   }
   __syncthreads();
 
-  // ---- scalar chain ---------------------------------------------------------------------
+  // ---- scalar chain: wave 0 only, coefficients broadcast through LDS ------------------------
+  __shared__ float bc[8];
+  if (tid < 64) {
   float S[UPD_NSUM];
 #pragma unroll
   for (int k = 0; k < UPD_NSUM; ++k) S[k] = tot[k];
@@ -503,7 +505,6 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
     t_Wold = p.t_W[e];
     t_wgt = (1.0f - p.t_mask) * (t_ok ? 1.0f : 0.0f) * en;
     if (!t_ok) logp_now = p.bk_logp[e];
-    __syncthreads();                                        // everyone has read the adaptive state
     if (tid == 0) {
       p.t_eps[e] = en;
       p.t_eps_max[e] = emax;
@@ -514,7 +515,6 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
   }
   if (p.flags & UPD_OB) ch.O(3, p.hB * eps, L, d);
   if (p.flags & UPD_B2) dk += ch.B(eps, p.coef_b2, gn, d);
-  __syncthreads();
   if (tid == 0) {
     p.dK[e] = dk;
     p.lold[e] = lold;
@@ -524,12 +524,17 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
       p.out_info[3 * e + 1] = info_dk;
       p.out_info[3 * e + 2] = info_de;
     }
+    bc[0] = ch.c[0]; bc[1] = ch.c[1] * ign; bc[2] = ch.c[2]; bc[3] = ch.c[3];
+    bc[4] = eps * p.coef_a; bc[5] = t_ok ? 1.0f : 0.0f; bc[6] = t_Wold; bc[7] = t_wgt;
   }
+  }
+  __syncthreads();
   // ---- pass 2 (from registers) ------------------------------------------------------------
   const bool any_op = p.flags & (UPD_B1 | UPD_OA | UPD_OB | UPD_B2);
   const bool doA = p.flags & UPD_A;
-  const float c0 = ch.c[0], c1 = ch.c[1] * ign, c2 = ch.c[2], c3 = ch.c[3];
-  const float ea = eps * p.coef_a;
+  const float c0 = bc[0], c1 = bc[1], c2 = bc[2], c3 = bc[3], ea = bc[4];
+  const bool t_ok = bc[5] != 0.0f;
+  const float t_Wold = bc[6], t_wgt = bc[7];
   if (tune && !t_ok) {   // handle_nans: this chain keeps its previous state (rare, workgroup-uniform)
     for (int i = tid; i < d; i += UPD_NT) {
       p.x[base + i] = p.bk_x[base + i];
