@@ -540,7 +540,7 @@ int32_t mile_step(mile_sampler *s, mile_state *state, const mile_step_args *a, v
     if (rc) return rc;
     {  // B(1 - 2 b1) . A(1/2)
       UpdParams u = up;
-      u.flags = UPD_FROM_SLABS | UPD_B1 | UPD_A;
+      u.flags = UPD_FROM_SLABS | UPD_B1 | UPD_A | UPD_NO_G;
       u.coef_b1 = b2; u.coef_a = 0.5f;
       launch_update(u, E, st);
     }
@@ -553,7 +553,7 @@ int32_t mile_step(mile_sampler *s, mile_state *state, const mile_step_args *a, v
       u.coef_b1 = b1;
       u.zA = noise_at(i, 1); u.stepA = (uint32_t)gstep; u.stageA = 1; u.hA = oso ? 0.5f : 1.0f;
       if (!last) {
-        u.flags |= UPD_B2 | UPD_A | (oso ? UPD_OB : 0);
+        u.flags |= UPD_B2 | UPD_A | (oso ? UPD_OB : 0) | UPD_NO_G;
         u.zB = noise_at(i + 1, 0); u.stepB = (uint32_t)(gstep + 1); u.stageB = 0; u.hB = 0.5f;
         u.coef_b2 = b1; u.coef_a = 0.5f;
       }
@@ -622,7 +622,7 @@ int32_t mile_tune(mile_sampler *s, mile_state *state, const mile_tune_args *a, v
     {
       UpdParams u = up;
       set_state(u, nxt);
-      u.flags = UPD_FROM_SLABS | UPD_B1 | UPD_A;
+      u.flags = UPD_FROM_SLABS | UPD_B1 | UPD_A | UPD_NO_G;
       u.coef_b1 = b2; u.coef_a = 0.5f;
       launch_update(u, E, st);
     }

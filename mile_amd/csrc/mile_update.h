@@ -25,6 +25,7 @@ enum : int32_t {
   UPD_B2 = 1 << 6,          // B(coef_b2) after the record point
   UPD_A = 1 << 7,           // position update with coef_a
   UPD_TUNE = 1 << 8,        // record point also runs the warm-up tuner (k_update_fast only)
+  UPD_NO_G = 1 << 9,        // mid-sequence launch: nobody reads state.g before the next gradient, skip its store (k_update_fast only)
 };
 
 struct UpdParams {
@@ -323,7 +324,6 @@ __device__ __forceinline__ void st4(float *q, const f32x4 v) {
 template <int NK, int AL, bool SDC>
 __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
   __shared__ float red[UPD_NW][UPD_NSUM + 1];
-  __shared__ float tot[UPD_NSUM + 1];
   const int tid = threadIdx.x, e = blockIdx.x, d = p.d;
   const size_t base = (size_t)e * d;
   const int nqf = d >> 2;            // full quads
@@ -335,8 +335,18 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
   const float *sl = p.slabs + (size_t)e * p.S * p.dp;
   const float *xin = p.x_in ? p.x_in : p.x, *uin = p.u_in ? p.u_in : p.u, *gin = p.g_in ? p.g_in : p.g;
   const bool tune = p.flags & UPD_TUNE;
+  const bool store_g = from_slabs && !(p.flags & UPD_NO_G);
   const float ips = 1.0f / p.prior_scale;
   const bool normal = p.prior == MILE_PRIOR_NORMAL;
+
+  // per-particle scalars, fetched up front so their latency hides under the vector loads
+  const float eps_in = p.eps[e], L_in = p.L[e];
+  const float dk_in = (p.flags & UPD_START) ? 0.0f : p.dK[e];
+  const float lold_in = (p.flags & UPD_START) ? 0.0f : p.lold[e];
+  const float logp_in = from_slabs ? 0.0f : (p.logp_in ? p.logp_in : p.logp)[e];
+  float ll_in = 0.0f;
+  if (from_slabs)
+    for (int s = 0; s < p.S; ++s) ll_in += p.llpart[(size_t)e * p.S + s];
 
   f32x4 cx[NK], cu[NK], cg[NK], ca[NK], cb[NK], csd[SDC ? NK : 1];
   // ---- pass 1: loads -----------------------------------------------------------------
@@ -400,7 +410,7 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
       sm[6] = fmaf(ui, b, sm[6]); sm[7] = fmaf(gs, b, sm[7]); sm[8] = fmaf(b, b, sm[8]);
       sm[9] = fmaf(a, b, sm[9]);
     }
-    if (from_slabs && q < nqf) st4<AL>(p.g + base + 4 * (size_t)q, cg[k]);
+    if (store_g && q < nqf) st4<AL>(p.g + base + 4 * (size_t)q, cg[k]);
     if constexpr (SDC) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) cg[k][m] *= csd[k][m];   // keep g~ = g*s for pass 2
@@ -418,7 +428,7 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
       const float tt = (tx - p.prior_loc) * ips;
       if (normal) { tg = fmaf(-tt, ips, tg); sm[10] = fmaf(-0.5f * mk * tt, tt, sm[10]); }
       else { tg -= (tt > 0.0f ? ips : (tt < 0.0f ? -ips : 0.0f)); sm[10] -= mk * fabsf(tt); }
-      if (has_tail) p.g[to] = tg;
+      if (has_tail && store_g) p.g[to] = tg;
     }
     if (tune) sm[11] += (has_tail && !isfinite(tx)) ? 1.0f : 0.0f;
     tg *= tsd;
@@ -435,30 +445,28 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
 #pragma unroll
     for (int k = 0; k < UPD_NSUM; ++k) red[tid >> 6][k] = sm[k];
   __syncthreads();
-  if (tid < UPD_NSUM) {
-    float t = 0.0f;
-#pragma unroll
-    for (int w = 0; w < UPD_NW; ++w) t += red[w][tid];
-    tot[tid] = t;
-  }
-  __syncthreads();
 
   // ---- scalar chain: wave 0 only, coefficients broadcast through LDS ------------------------
   __shared__ float bc[8];
   if (tid < 64) {
   float S[UPD_NSUM];
+  {
+    float t = 0.0f;
+    const int kk = tid < UPD_NSUM ? tid : 0;
 #pragma unroll
-  for (int k = 0; k < UPD_NSUM; ++k) S[k] = tot[k];
-  const float eps = p.eps[e], L = p.L[e];
+    for (int w = 0; w < UPD_NW; ++w) t += red[w][kk];
+#pragma unroll
+    for (int k = 0; k < UPD_NSUM; ++k) S[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), k));
+  }
+  const float eps = eps_in, L = L_in;
   float logp_now;
   if (from_slabs) {
-    float ll = 0.0f;
-    for (int s = 0; s < p.S; ++s) ll += p.llpart[(size_t)e * p.S + s];
+    const float ll = ll_in;
     const float cst = normal ? -(float)d * (logf(p.prior_scale) + 0.91893853320467274f)
                              : -(float)d * logf(2.0f * p.prior_scale);
     logp_now = ll + (S[10] + cst);
   } else {
-    logp_now = (p.logp_in ? p.logp_in : p.logp)[e];
+    logp_now = logp_in;
   }
   const float gn = S[2] > 0.0f ? sqrtf(S[2]) : 1.0f;
   const float ign = 1.0f / gn;
@@ -473,8 +481,8 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
     for (int b = 0; b < 4; ++b)
       if (b < a) ch.M[a][b] = ch.M[b][a];
   ch.c[0] = 1.0f; ch.c[1] = ch.c[2] = ch.c[3] = 0.0f;
-  float dk = (p.flags & UPD_START) ? 0.0f : p.dK[e];
-  float lold = (p.flags & UPD_START) ? logp_now : p.lold[e];
+  float dk = (p.flags & UPD_START) ? 0.0f : dk_in;
+  float lold = (p.flags & UPD_START) ? logp_now : lold_in;
   if (p.flags & UPD_B1) dk += ch.B(eps, p.coef_b1, gn, d);
   if (p.flags & UPD_OA) ch.O(2, p.hA * eps, L, d);
   float info_dk = 0.0f, info_de = 0.0f;
