@@ -1,0 +1,65 @@
+// bf16 MFMA fragment helpers for gfx950 (v_mfma_f32_32x32x16_bf16) over swizzled LDS images.
+//
+// An "image" is a [rows][128] bf16 array in LDS with 256-byte rows whose 16-byte chunks are XOR
+// swizzled so that BOTH kinds of operand read are bank-conflict free:
+//   * row reads (ds_read_b128): a lane takes 8 consecutive columns of one row;
+//   * transposed reads (ds_read_b64_tr_b16): a lane takes 8 consecutive ROWS of one column.
+// Operand maps (lane l: r = l & 31, h = l >> 5; fragment element j = 0..7):
+//   A[m = r][k = 8h + j],  B[k = 8h + j][n = r],  D[m = (reg&3) + 8(reg>>2) + 4h][n = r].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define MILE_LDS_PTR(T, p) ((__attribute__((address_space(3))) T *)(p))
+
+// byte offset of 16-byte chunk `ch` (0..15) of row `row` inside an image
+__device__ __forceinline__ int img_off(int row, int ch) {
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+// 8 consecutive columns [8*ch, 8*ch+8) of `row`
+__device__ __forceinline__ bf16x8 row_frag(const char *img, int row, int ch) {
+  return *reinterpret_cast<const bf16x8 *>(img + img_off(row, ch));
+}
+
+// Transposed fragment: element j of lane (r, h) = img[row0 + 8h + j][col0 + r], for a 32-column
+// block starting at col0 (multiple of 32) and 16 rows starting at row0 (multiple of 16).
+// ds_read_b64_tr_b16 works per 16-lane group: lane 4q+p of the group supplies the address of row q,
+// columns 4p..4p+3 of a 4 x 16 block and receives column (lane & 15) of the 4 rows.  All 64 lanes
+// must be active.
+__device__ __forceinline__ bf16x8 tr_frag(const char *img, int row0, int col0, int lane) {
+  const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
+  const int row = row0 + 8 * h + q;
+  const int ch = (col0 >> 3) + 2 * g1 + (p >> 1);
+  const char *a0 = img + img_off(row, ch) + 8 * (p & 1);
+  const char *a1 = img + img_off(row + 4, ch) + 8 * (p & 1);
+  const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, a0));
+  const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, a1));
+  return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// Store a 32x32 accumulator tile D[m = feature][n = row] as img[row = n][col0 + m] (bf16).
+__device__ __forceinline__ void store_tile(char *img, int col0, const f32x16 &acc, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4_t v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    const bf16x4 b = __builtin_convertvector(v, bf16x4);
+    *reinterpret_cast<bf16x4 *>(img + img_off(r, (col0 >> 3) + g) + 8 * h) = b;
+  }
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// feature index (within a 32-block) that accumulator register j of lane half h holds
+__device__ __forceinline__ int acc_m(int j, int h) { return (j & 3) + 8 * (j >> 2) + 4 * h; }
