@@ -57,8 +57,14 @@ typedef enum mile_task { MILE_TASK_REGRESSION = 0, MILE_TASK_CLASSIFICATION = 1 
 typedef enum mile_prior { MILE_PRIOR_NORMAL = 0, MILE_PRIOR_LAPLACE = 1 } mile_prior;
 /* Placement of the partial momentum refresh inside one kernel step. */
 typedef enum mile_refresh { MILE_REFRESH_O_STEP_O = 0, MILE_REFRESH_STEP_O = 1 } mile_refresh;
-/* Which grad-log-posterior kernel to use.  AUTO picks the fastest that supports the spec. */
-typedef enum mile_grad_kernel { MILE_GRAD_AUTO = 0, MILE_GRAD_GENERIC = 1, MILE_GRAD_MFMA_W64 = 2 } mile_grad_kernel;
+/* Which grad-log-posterior kernel to use.  AUTO picks the fastest fp32 kernel that supports the spec;
+ * the bf16-operand kernel (fp32 accumulate, fp32 parameters) is only ever selected explicitly. */
+typedef enum mile_grad_kernel {
+  MILE_GRAD_AUTO = 0,
+  MILE_GRAD_GENERIC = 1,          /* any FCN, fp32 VALU */
+  MILE_GRAD_MFMA_W64 = 2,         /* ReLU regression, 1-3 hidden layers of width 64, fp32 MFMA */
+  MILE_GRAD_MFMA_W128_BF16 = 3    /* ReLU regression, 1-3 hidden layers of width 128, bf16 MFMA */
+} mile_grad_kernel;
 
 /* FCNConfig (src/config/models/fcn.py:7-30) + PriorConfig (src/config/sampler.py:60-95)
  * + Task: everything log_unnormalized_posterior (src/training/probabilistic.py:115-138)

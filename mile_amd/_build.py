@@ -13,8 +13,8 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / 'csrc'
 LIB_PATH = PKG_DIR / 'libmile_hip.so'
 SOURCES = ['mile_hip.hip']
-HEADERS = ['mile_device.h', 'mile_grad_generic.h', 'mile_grad_w64.h', 'mile_grad_w64_block.inc', 'mile_predict.h',
-           'mile_update.h']
+HEADERS = ['mile_device.h', 'mile_grad_generic.h', 'mile_grad_w64.h', 'mile_grad_w64_block.inc', 'mile_bf16_frag.h',
+           'mile_grad_w128b.h', 'mile_predict.h', 'mile_update.h']
 
 
 def _hipcc() -> str:

@@ -14,6 +14,8 @@ struct GradParams {
   const float *theta;   // [E, d]
   const float *X;       // [N, F]
   const float *Xp;      // [Npad, Fp] zero padded (MFMA kernels)
+  const void *Xb;       // [Npad, 16] bf16 zero padded, and
+  const void *Xt;       // [32, Npad] bf16 transposed (k_grad_w128b)
   const void *y;        // [Npad] fp32 (regr) or int32 (classification)
   float *slabs;         // [E, S, d]
   float *llpart;        // [E, S]

@@ -13,6 +13,7 @@
 #include "mile_device.h"
 #include "mile_grad_generic.h"
 #include "mile_grad_w64.h"
+#include "mile_grad_w128b.h"
 #include "mile_predict.h"
 #include "mile_update.h"
 
@@ -34,6 +35,7 @@ struct mile_sampler {
   int n_cu = 256;
   // data
   float *X = nullptr, *Xp = nullptr;
+  void *Xb = nullptr, *Xt = nullptr;   // bf16 copies for k_grad_w128b
   void *y = nullptr;
   int N = 0, Npad = 0, Fp = 0;
   // workspace
@@ -59,6 +61,17 @@ static bool w64_supported(const mile_model_spec &sp) {
   return true;
 }
 
+static bool w128b_supported(const mile_model_spec &sp) {
+  if (sp.task != MILE_TASK_REGRESSION || sp.activation != MILE_ACT_RELU) return false;
+  const int nh = sp.n_layers - 1;
+  if (nh < 1 || nh > 3) return false;
+  for (int l = 0; l < nh; ++l)
+    if (sp.widths[l] != 128) return false;
+  if (sp.widths[nh] != 2) return false;
+  if (sp.in_features > 16) return false;
+  return true;
+}
+
 static int resolved_kernel(const mile_sampler *s) {
   if (s->grad_kernel == MILE_GRAD_AUTO) return w64_supported(s->spec) ? MILE_GRAD_MFMA_W64 : MILE_GRAD_GENERIC;
   return s->grad_kernel;
@@ -78,6 +91,11 @@ static int choose_S(const mile_sampler *s, int E, int kernel) {
     int S = std::max(1, s->n_cu / std::max(E, 1));
     S = std::min(S, std::max(1, NB / 4));  // keep >= 4 row blocks (one per wave) per workgroup
     return S;
+  }
+  if (kernel == MILE_GRAD_MFMA_W128_BF16) {
+    const int NB = s->Npad / 32;
+    int S = std::max(1, s->n_cu / std::max(E, 1));
+    return std::min(S, std::max(1, NB / 8));  // amortise weight staging over >= 8 row tiles
   }
   int S = std::max(1, (2 * s->n_cu) / std::max(E, 1));
   S = std::min(S, std::max(1, s->N / 64));
@@ -155,7 +173,9 @@ static void free_data(mile_sampler *s) {
   if (s->X) (void)hipFree(s->X);
   if (s->Xp) (void)hipFree(s->Xp);
   if (s->y) (void)hipFree(s->y);
-  s->X = s->Xp = nullptr; s->y = nullptr;
+  if (s->Xb) (void)hipFree(s->Xb);
+  if (s->Xt) (void)hipFree(s->Xt);
+  s->X = s->Xp = nullptr; s->y = nullptr; s->Xb = s->Xt = nullptr;
 }
 static void free_ws(mile_sampler *s) {
   if (s->slabs) (void)hipFree(s->slabs);
@@ -199,6 +219,15 @@ __global__ void k_pad_x(const float *X, float *Xp, int N, int Npad, int F, int F
   Xp[idx] = (r < N && c < F) ? X[(long long)r * F + c] : 0.0f;
 }
 
+__global__ void k_prep_bf16(const float *X, bf16 *Xb, bf16 *Xt, int N, int Npad, int F) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)Npad * 32) return;
+  const int r = (int)(idx >> 5), c = (int)(idx & 31);
+  const bf16 v = (bf16)((r < N && c < F) ? X[(long long)r * F + c] : 0.0f);
+  if (c < 16) Xb[(long long)r * 16 + c] = v;
+  Xt[(long long)c * Npad + r] = v;
+}
+
 int32_t mile_set_data(mile_sampler *s, const float *X, const void *y, int64_t N, void *stream) {
   if (!s || !X || !y) return fail(MILE_ERR_INVALID, "mile_set_data: null argument");
   if (N < 1 || N > 0x3fffffff) return fail(MILE_ERR_INVALID, "mile_set_data: N out of range");
@@ -219,6 +248,13 @@ int32_t mile_set_data(mile_sampler *s, const float *X, const void *y, int64_t N,
   const long long tot = (long long)s->Npad * s->Fp;
   k_pad_x<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(s->X, s->Xp, s->N, s->Npad, F, s->Fp);
   HIP_TRY(hipGetLastError());
+  if (w128b_supported(s->spec)) {
+    HIP_TRY(hipMalloc(&s->Xb, (size_t)s->Npad * 16 * 2));
+    HIP_TRY(hipMalloc(&s->Xt, (size_t)s->Npad * 32 * 2));
+    const long long tb = (long long)s->Npad * 32;
+    k_prep_bf16<<<(unsigned)((tb + 255) / 256), 256, 0, st>>>(s->X, (bf16 *)s->Xb, (bf16 *)s->Xt, s->N, s->Npad, F);
+    HIP_TRY(hipGetLastError());
+  }
   return MILE_OK;
 }
 
@@ -227,8 +263,8 @@ int32_t mile_reserve(mile_sampler *s, int32_t E) {
   if (!s->X) return fail(MILE_ERR_STATE, "mile_reserve: call mile_set_data first");
   HIP_TRY(hipSetDevice(s->device));
   // capacity must cover whichever grad kernel is selected later
-  const int S = std::max(choose_S(s, E, MILE_GRAD_GENERIC),
-                         w64_supported(s->spec) ? choose_S(s, E, MILE_GRAD_MFMA_W64) : 1);
+  int S = std::max(choose_S(s, E, MILE_GRAD_GENERIC), w64_supported(s->spec) ? choose_S(s, E, MILE_GRAD_MFMA_W64) : 1);
+  if (w128b_supported(s->spec)) S = std::max(S, choose_S(s, E, MILE_GRAD_MFMA_W128_BF16));
   if (E <= s->E_cap && S <= s->S_cap) return MILE_OK;
   free_ws(s);
   HIP_TRY(hipMalloc(&s->slabs, (size_t)E * S * ((s->ds.d + 3) / 4 * 4) * 4));
@@ -246,7 +282,9 @@ int32_t mile_reserve(mile_sampler *s, int32_t E) {
 
 int32_t mile_set_grad_kernel(mile_sampler *s, int32_t which) {
   if (!s) return fail(MILE_ERR_INVALID, "null handle");
-  if (which < MILE_GRAD_AUTO || which > MILE_GRAD_MFMA_W64) return fail(MILE_ERR_INVALID, "unknown grad kernel");
+  if (which < MILE_GRAD_AUTO || which > MILE_GRAD_MFMA_W128_BF16) return fail(MILE_ERR_INVALID, "unknown grad kernel");
+  if (which == MILE_GRAD_MFMA_W128_BF16 && !w128b_supported(s->spec))
+    return fail(MILE_ERR_INVALID, "MFMA_W128_BF16 needs ReLU regression with 1-3 hidden layers of width 128 and F <= 16");
   if (which == MILE_GRAD_MFMA_W64 && !w64_supported(s->spec))
     return fail(MILE_ERR_INVALID, "MFMA_W64 needs ReLU regression with 1-3 hidden layers of width 64 and F <= 16");
   s->grad_kernel = which;
@@ -311,6 +349,19 @@ static hipError_t launch_w64(const GradParams &gp, int E, hipStream_t st) {
   return hipGetLastError();
 }
 
+template <int NH>
+static hipError_t launch_w128b(const GradParams &gp, int E, hipStream_t st) {
+  using LY = W128Layout<NH>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)k_grad_w128b<NH>, hipFuncAttributeMaxDynamicSharedMemorySize, LY::BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  k_grad_w128b<NH><<<dim3(gp.S, E), 256, LY::BYTES, st>>>(gp);
+  return hipGetLastError();
+}
+
 template <int NH, int FQ>
 static int w64_lds_bytes() { return W64Layout<NH, FQ>::BYTES; }
 
@@ -322,7 +373,7 @@ static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t s
   GradParams gp;
   gp.spec = s->ds;
   gp.theta = theta;
-  gp.X = s->X; gp.Xp = s->Xp; gp.y = s->y;
+  gp.X = s->X; gp.Xp = s->Xp; gp.y = s->y; gp.Xb = s->Xb; gp.Xt = s->Xt;
   gp.slabs = s->slabs; gp.llpart = s->llpart;
   gp.N = s->N; gp.Npad = s->Npad; gp.Fp = s->Fp; gp.S = S; gp.R = generic_R(s->ds); gp.dp = (s->ds.d + 3) / 4 * 4;
   { const char *dv = getenv("MILE_DEBUG"); gp.dbg = dv ? atoi(dv) : 0; }
@@ -348,6 +399,14 @@ static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t s
     else if (nh == 1 && fq == 2) e = launch_w64<1, 2>(gp, E, st);
     else if (nh == 2 && fq == 2) e = launch_w64<2, 2>(gp, E, st);
     else if (nh == 3 && fq == 2) e = launch_w64<3, 2>(gp, E, st);
+    HIP_TRY(e);
+  } else if (kernel == MILE_GRAD_MFMA_W128_BF16) {
+    if (!s->Xb) return fail(MILE_ERR_STATE, "bf16 data copies missing: call mile_set_data");
+    const int nh = s->spec.n_layers - 1;
+    hipError_t e = hipErrorInvalidValue;
+    if (nh == 1) e = launch_w128b<1>(gp, E, st);
+    else if (nh == 2) e = launch_w128b<2>(gp, E, st);
+    else if (nh == 3) e = launch_w128b<3>(gp, E, st);
     HIP_TRY(e);
   } else {
     const size_t lds = ((size_t)gp.R * (s->ds.act_stride + 2 * s->ds.max_width) + 16) * 4;
@@ -436,6 +495,10 @@ int32_t mile_grad_launch_info(const mile_sampler *s, int32_t E, int32_t *grid_x,
     lds = nh == 1 ? (fq == 1 ? w64_lds_bytes<1, 1>() : w64_lds_bytes<1, 2>())
         : nh == 2 ? (fq == 1 ? w64_lds_bytes<2, 1>() : w64_lds_bytes<2, 2>())
                   : (fq == 1 ? w64_lds_bytes<3, 1>() : w64_lds_bytes<3, 2>());
+  } else if (kernel == MILE_GRAD_MFMA_W128_BF16) {
+    const int nh = s->spec.n_layers - 1;
+    nm = "k_grad_w128b";
+    lds = nh == 1 ? W128Layout<1>::BYTES : nh == 2 ? W128Layout<2>::BYTES : W128Layout<3>::BYTES;
   } else {
     lds = (int)(((size_t)generic_R(s->ds) * (s->ds.act_stride + 2 * s->ds.max_width) + 16) * 4);
   }

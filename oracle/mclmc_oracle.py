@@ -296,6 +296,49 @@ def logpost_and_grad(spec: ModelSpec, theta: np.ndarray, X: np.ndarray, y: np.nd
     return logp.astype(dt), (grad + gp).astype(dt)
 
 
+def bf16_round(x: np.ndarray) -> np.ndarray:
+    """Round to the nearest bfloat16 (8-bit significand, ties to even), returned in x's dtype."""
+    f = np.ascontiguousarray(x, dtype=np.float32)
+    u = f.view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    r = u.astype(np.uint32).view(np.float32)
+    return np.where(np.isfinite(f), r, f).astype(x.dtype)
+
+
+def logpost_and_grad_bf16(spec: ModelSpec, theta: np.ndarray, X: np.ndarray, y: np.ndarray):
+    """logpost_and_grad under the mixed-precision recipe of BASELINE config 3 ("bf16"): every operand of a
+    matrix product (inputs, weights, activations, back-propagated signals) is rounded to bfloat16 where it
+    enters the product, accumulation and everything elementwise (bias add, ReLU, likelihood, prior) stay in
+    the working precision.  ReLU derivatives come from the un-rounded pre-activations.  This is the checker
+    for the bf16-operand HIP kernel; same citations as logpost_and_grad."""
+    assert spec.activation == 'relu'
+    dt = theta.dtype
+    q = bf16_round
+    layers = unravel(spec, theta)
+    E = theta.shape[0]
+    h = np.broadcast_to(q(X.astype(dt)), (E,) + X.shape)
+    zs, hs = [], [h]
+    for li, (W, b) in enumerate(layers):
+        z = h @ q(W) + b[:, None, :]
+        zs.append(z)
+        h = q(np.maximum(z, 0)) if li < len(layers) - 1 else z
+        hs.append(h)
+    ll, dout = pointwise_loglik(spec, h, y)
+    lp, gp = log_prior(spec, theta)
+    grad = np.zeros_like(theta)
+    ents = param_slices(spec)
+    dz = q(dout)
+    for li in range(len(layers) - 1, -1, -1):
+        W, _ = layers[li]
+        k0, k1 = ents[li]['kernel']
+        grad[:, k0:k1] = (np.swapaxes(hs[li], 1, 2) @ dz).reshape(E, -1)
+        b0, b1 = ents[li]['bias']
+        grad[:, b0:b1] = dz.sum(axis=1)
+        if li > 0:
+            dz = q((dz @ np.swapaxes(q(W), 1, 2)) * (zs[li - 1] > 0))
+    return (lp + ll.sum(axis=-1)).astype(dt), (grad + gp).astype(dt)
+
+
 # --------------------------------------------------------------------------
 # MCLMC kernel (blackjax 1.2.2 semantics, SURVEY Appendix A)
 # --------------------------------------------------------------------------

@@ -64,6 +64,51 @@ def test_logpost_grad_matches_oracle(oracle, F, hs, act, task, prior, N, E, kern
         assert _relerr(g.cpu().numpy(), g_ref) < 2e-5, k
 
 
+BF16_CASES = [
+    # in_features, hidden, N, E   (ReLU regression, width 128: what k_grad_w128b supports)
+    (9, (128, 128, 128, 2), 1000, 5),
+    (9, (128, 128, 128, 2), 4096, 300),     # more particles than CUs, several row ranges
+    (5, (128, 128, 2), 33, 3),              # ragged second tile
+    (16, (128, 2), 257, 2),                 # F at the padding boundary, one hidden layer
+    (3, (128, 128, 128, 2), 2, 1),          # fewer rows than one tile
+]
+
+
+@pytest.mark.parametrize('F,hs,N,E', BF16_CASES)
+def test_bf16_w128_grad_matches_oracle(oracle, F, hs, N, E):
+    """bf16-operand MFMA kernel (config B3's precision) vs the oracle.  Operands are rounded to bf16 (8-bit
+    significand) where they enter a matrix product, accumulation is fp32.  Two checks: (1) against the
+    oracle's restatement of that same recipe in fp64 (logpost_and_grad_bf16): what is left is fp32
+    accumulation order plus the rare activation that lands on the other side of a bf16 rounding boundary
+    -> 2e-3 of each parameter leaf's gradient norm, 1e-4 on the log-posterior; (2) against the
+    full-precision fp64 oracle, the cost of the bf16 operands themselves -> 5e-2 of the whole gradient's
+    norm, 5e-3 on the log-posterior."""
+    ospec = oracle.ModelSpec(F, hs)
+    prob = oracle.synthetic_problem(ospec, N, E, seed=3)
+    lp_ref, g_ref = oracle.logpost_and_grad_bf16(ospec, prob['theta0'].astype(np.float64), prob['X'], prob['y'])
+    lp_full, g_full = oracle.logpost_and_grad(ospec, prob['theta0'].astype(np.float64), prob['X'], prob['y'])
+    eng = _engine(oracle, ospec, prob, 'mfma_w128_bf16')
+    assert eng.grad_kernel == 'mfma_w128_bf16'
+    lp, g = eng.logpost_grad(torch.from_numpy(prob['theta0']))
+    torch.cuda.synchronize()
+    lp, g = lp.cpu().numpy(), g.cpu().numpy().astype(np.float64)
+    assert np.isfinite(g).all()
+    assert _relerr(lp, lp_ref) < 1e-4
+    assert _relerr(lp, lp_full) < 5e-3
+    off = 0
+    fin = F
+    for li, wd in enumerate(hs):               # ravel order: bias, kernel per layer
+        for name, n in (('bias', wd), ('kernel', fin * wd)):
+            a, b = g[:, off:off + n], g_ref[:, off:off + n]
+            err = np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-30)
+            assert err.max() < 2e-3, (li, name, err.max())
+            off += n
+        fin = wd
+    assert off == ospec.n_params
+    tot = np.linalg.norm(g - g_full, axis=1) / np.linalg.norm(g_full, axis=1)
+    assert tot.max() < 5e-2, tot.max()
+
+
 def test_philox_noise_bits_match_oracle(oracle):
     ospec = oracle.ModelSpec(5, (16, 16, 2))
     prob = oracle.synthetic_problem(ospec, 64, 4)

@@ -251,3 +251,23 @@ def test_misc_golden():
     assert np.allclose(O.philox_normal(0x1234ABCD5678EF, z['philox_ids'], 9, 1, 37), z['philox_normal'], rtol=1e-13)
     assert np.allclose(O.effective_sample_size(z['ar1']), z['ar1_ess'], rtol=1e-10)
     assert abs(O.lppd(z['lppd_in']) - float(z['lppd_out'])) < 1e-13
+
+
+def test_bf16_round_matches_torch_and_recipe_is_close(oracle):
+    """bf16_round is round-to-nearest-even to 8 significand bits (checked against torch's conversion); the
+    bf16-operand recipe stays within a few percent of the full-precision gradient."""
+    torch = pytest.importorskip('torch')
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(4096) * 10.0 ** rng.integers(-20, 20, 4096),
+                        [0.0, -0.0, 1.0, 1.00390625, 1.01171875, 3.3e38, 1e-40]])
+    want = torch.tensor(x, dtype=torch.float32).to(torch.bfloat16).to(torch.float64).numpy()
+    got = oracle.bf16_round(x)
+    fin = np.isfinite(want)                  # values that round up to inf in bf16 are left to the caller
+    np.testing.assert_array_equal(got[fin], want[fin])
+    sp = oracle.ModelSpec(9, (128, 128, 2))
+    pr = oracle.synthetic_problem(sp, 200, 3, seed=3)
+    th = pr['theta0'].astype(np.float64)
+    lp, g = oracle.logpost_and_grad(sp, th, pr['X'], pr['y'])
+    lpb, gb = oracle.logpost_and_grad_bf16(sp, th, pr['X'], pr['y'])
+    assert np.abs(lpb - lp).max() < 5e-3 * np.abs(lp).max()
+    assert (np.linalg.norm(gb - g, axis=1) / np.linalg.norm(g, axis=1)).max() < 5e-2
