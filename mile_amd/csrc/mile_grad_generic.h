@@ -15,11 +15,12 @@ struct GradParams {
   const float *X;       // [N, F]
   const float *Xp;      // [Npad, Fp] zero padded (MFMA kernels)
   const void *Xb;       // [Npad, 16] bf16 zero padded, and
-  const void *Xt;       // [32, Npad] bf16 transposed (k_grad_w128b)
+  const void *Xt;       // [32, Npb] bf16 transposed (k_grad_w128b); Npb = N rounded up to 64 rows
   const void *y;        // [Npad] fp32 (regr) or int32 (classification)
   float *slabs;         // [E, S, d]
   float *llpart;        // [E, S]
   int32_t N, Npad, Fp, S, R;
+  int32_t Npb;
   int32_t dp;           // slab row stride: d rounded up to a multiple of 4 floats (128-bit stores)
   int32_t dbg;          // debug knobs (MILE_DEBUG env): bit0 skip row blocks, bit1 skip staging, bit2 skip reduction
 };

@@ -37,7 +37,7 @@ struct mile_sampler {
   float *X = nullptr, *Xp = nullptr;
   void *Xb = nullptr, *Xt = nullptr;   // bf16 copies for k_grad_w128b
   void *y = nullptr;
-  int N = 0, Npad = 0, Fp = 0;
+  int N = 0, Npad = 0, Fp = 0, Npb = 0;
   // workspace
   int E_cap = 0, S_cap = 0;
   float *slabs = nullptr, *llpart = nullptr, *dK = nullptr, *lold = nullptr;
@@ -93,9 +93,9 @@ static int choose_S(const mile_sampler *s, int E, int kernel) {
     return S;
   }
   if (kernel == MILE_GRAD_MFMA_W128_BF16) {
-    const int NB = s->Npad / 32;
+    const int NBS = s->Npb / 64;              // iterations of two 32-row tiles
     int S = std::max(1, s->n_cu / std::max(E, 1));
-    return std::min(S, std::max(1, NB / 8));  // amortise weight staging over >= 8 row tiles
+    return std::min(S, std::max(1, NBS / 4));  // amortise weight staging over >= 8 row tiles
   }
   int S = std::max(1, (2 * s->n_cu) / std::max(E, 1));
   S = std::min(S, std::max(1, s->N / 64));
@@ -249,10 +249,11 @@ int32_t mile_set_data(mile_sampler *s, const float *X, const void *y, int64_t N,
   k_pad_x<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(s->X, s->Xp, s->N, s->Npad, F, s->Fp);
   HIP_TRY(hipGetLastError());
   if (w128b_supported(s->spec)) {
-    HIP_TRY(hipMalloc(&s->Xb, (size_t)s->Npad * 16 * 2));
-    HIP_TRY(hipMalloc(&s->Xt, (size_t)s->Npad * 32 * 2));
-    const long long tb = (long long)s->Npad * 32;
-    k_prep_bf16<<<(unsigned)((tb + 255) / 256), 256, 0, st>>>(s->X, (bf16 *)s->Xb, (bf16 *)s->Xt, s->N, s->Npad, F);
+    s->Npb = ((int)N + 63) / 64 * 64;
+    HIP_TRY(hipMalloc(&s->Xb, (size_t)s->Npb * 16 * 2));
+    HIP_TRY(hipMalloc(&s->Xt, (size_t)s->Npb * 32 * 2));
+    const long long tb = (long long)s->Npb * 32;
+    k_prep_bf16<<<(unsigned)((tb + 255) / 256), 256, 0, st>>>(s->X, (bf16 *)s->Xb, (bf16 *)s->Xt, s->N, s->Npb, F);
     HIP_TRY(hipGetLastError());
   }
   return MILE_OK;
@@ -351,14 +352,14 @@ static hipError_t launch_w64(const GradParams &gp, int E, hipStream_t st) {
 
 template <int NH>
 static hipError_t launch_w128b(const GradParams &gp, int E, hipStream_t st) {
-  using LY = W128Layout<NH>;
+  using LY = W128Layout<NH, 2>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_grad_w128b<NH>, hipFuncAttributeMaxDynamicSharedMemorySize, LY::BYTES);
+    hipError_t e = hipFuncSetAttribute((const void *)k_grad_w128b<NH, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LY::BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  k_grad_w128b<NH><<<dim3(gp.S, E), 256, LY::BYTES, st>>>(gp);
+  k_grad_w128b<NH, 2><<<dim3(gp.S, E), 256, LY::BYTES, st>>>(gp);
   return hipGetLastError();
 }
 
@@ -375,7 +376,7 @@ static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t s
   gp.theta = theta;
   gp.X = s->X; gp.Xp = s->Xp; gp.y = s->y; gp.Xb = s->Xb; gp.Xt = s->Xt;
   gp.slabs = s->slabs; gp.llpart = s->llpart;
-  gp.N = s->N; gp.Npad = s->Npad; gp.Fp = s->Fp; gp.S = S; gp.R = generic_R(s->ds); gp.dp = (s->ds.d + 3) / 4 * 4;
+  gp.N = s->N; gp.Npad = s->Npad; gp.Npb = s->Npb; gp.Fp = s->Fp; gp.S = S; gp.R = generic_R(s->ds); gp.dp = (s->ds.d + 3) / 4 * 4;
   { const char *dv = getenv("MILE_DEBUG"); gp.dbg = dv ? atoi(dv) : 0; }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (s->timing) {
@@ -498,7 +499,7 @@ int32_t mile_grad_launch_info(const mile_sampler *s, int32_t E, int32_t *grid_x,
   } else if (kernel == MILE_GRAD_MFMA_W128_BF16) {
     const int nh = s->spec.n_layers - 1;
     nm = "k_grad_w128b";
-    lds = nh == 1 ? W128Layout<1>::BYTES : nh == 2 ? W128Layout<2>::BYTES : W128Layout<3>::BYTES;
+    lds = nh == 1 ? W128Layout<1, 2>::BYTES : nh == 2 ? W128Layout<2, 2>::BYTES : W128Layout<3, 2>::BYTES;
   } else {
     lds = (int)(((size_t)generic_R(s->ds) * (s->ds.act_stride + 2 * s->ds.max_width) + 16) * 4);
   }

@@ -79,8 +79,9 @@ def test_bf16_w128_grad_matches_oracle(oracle, F, hs, N, E):
     """bf16-operand MFMA kernel (config B3's precision) vs the oracle.  Operands are rounded to bf16 (8-bit
     significand) where they enter a matrix product, accumulation is fp32.  Two checks: (1) against the
     oracle's restatement of that same recipe in fp64 (logpost_and_grad_bf16): what is left is fp32
-    accumulation order plus the rare activation that lands on the other side of a bf16 rounding boundary
-    -> 2e-3 of each parameter leaf's gradient norm, 1e-4 on the log-posterior; (2) against the
+    accumulation order (typically 1e-5) plus the rare activation that lands on the other side of a bf16
+    rounding boundary or of the ReLU kink (one such flip moves a leaf by ~2e-3)
+    -> 5e-3 of each parameter leaf's gradient norm, 1e-4 on the log-posterior; (2) against the
     full-precision fp64 oracle, the cost of the bf16 operands themselves -> 5e-2 of the whole gradient's
     norm, 5e-3 on the log-posterior."""
     ospec = oracle.ModelSpec(F, hs)
@@ -101,7 +102,7 @@ def test_bf16_w128_grad_matches_oracle(oracle, F, hs, N, E):
         for name, n in (('bias', wd), ('kernel', fin * wd)):
             a, b = g[:, off:off + n], g_ref[:, off:off + n]
             err = np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-30)
-            assert err.max() < 2e-3, (li, name, err.max())
+            assert err.max() < 5e-3, (li, name, err.max())
             off += n
         fin = wd
     assert off == ospec.n_params
