@@ -30,13 +30,15 @@
 template <int NH, int RT>
 struct W128Layout {
   static constexpr int WIMG = 0;                              // W_2..W_NH: [128 in][128 out] bf16, 32 KiB each
-  static constexpr int WOT = WIMG + (NH - 1) * 32768;         // head weights transposed: [16 (k, zero padded)][128 in]
-  static constexpr int TILE = WOT + 4096;                     // per row tile: H_1..H_NH, dZ ping-pong ([32][128] each)
+  static constexpr int TILE = WIMG + (NH - 1) * 32768;        // per row tile: H_1..H_NH, dZ ping-pong ([32][128] each)
   static constexpr int HIMG = 0;                              //   offsets inside a tile set
-  static constexpr int DZ = NH * 8192;                        //   d(out) aliases DZ[1] (free while it is live)
+  static constexpr int DZ = NH * 8192;
   static constexpr int TILE_BYTES = (NH + 2) * 8192;
   static constexpr int BIAS = TILE + RT * TILE_BYTES;         // bias tiles in accumulator layout: [NH][4 waves][2 halves][16] fp32
-  static constexpr int BYTES = BIAS + NH * 4 * 2 * 16 * 4;
+  static constexpr int PART = BIAS + NH * 4 * 2 * 16 * 4;     // head partial sums: [RT][4 waves][32 rows][2] fp32
+  static constexpr int DOP = PART + RT * 4 * 32 * 2 * 4;      // per-wave transposed d(out): [4 waves][RT][2][32 rows] bf16
+  static constexpr int ZERO = DOP + 4 * RT * 2 * 32 * 2;      // 16 zero bytes
+  static constexpr int BYTES = ZERO + 16;
 };
 
 __device__ __forceinline__ float bf16_colsum(const bf16x8 v, float acc) {   // acc + sum of the 8 elements
@@ -53,15 +55,31 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
 // H = relu(z) as bf16 into the image: rounding and ReLU commute, and on bf16 bit patterns ReLU is a signed
 // 16-bit max with 0 (v_pk_max_i16), two elements per instruction.
-__device__ __forceinline__ void store_tile_relu(char *img, int col0, const f32x16 &z, int lane) {
+__device__ __forceinline__ void store_tile_relu(char *img, int col0, const f32x16 &z, int lane, s16x4 packed[4]) {
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const f32x4_t v = {z[4 * g], z[4 * g + 1], z[4 * g + 2], z[4 * g + 3]};
     const s16x4 b = __builtin_bit_cast(s16x4, __builtin_convertvector(v, bf16x4));
     const s16x4 zero = {0, 0, 0, 0};
-    *reinterpret_cast<s16x4 *>(img + img_off(r, (col0 >> 3) + g) + 8 * h) = __builtin_elementwise_max(b, zero);
+    packed[g] = __builtin_elementwise_max(b, zero);
+    *reinterpret_cast<s16x4 *>(img + img_off(r, (col0 >> 3) + g) + 8 * h) = packed[g];
   }
+}
+
+// one 4-feature group of a masked dZ store; hb = this lane's 4 H values (bit patterns) of that group
+__device__ __forceinline__ void store_group_masked(char *dst, const f32x4_t v, const f32x2_t hb) {
+  const uint32_t ones = 0x00010001u;
+  const f32x2_t b = __builtin_bit_cast(f32x2_t, __builtin_convertvector(v, bf16x4));
+  f32x2_t o;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    float m, t;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(hb[k]), "v"(ones));
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(t) : "v"(b[k]), "v"(m));
+    o[k] = t;
+  }
+  *reinterpret_cast<f32x2_t *>(dst) = o;
 }
 
 // dZ = dH * relu'(z) as bf16 into dzimg; relu'(z) = (H != 0) is read back from this wave's own slice of the
@@ -116,15 +134,21 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
       *reinterpret_cast<bf16x8 *>(img + img_off(row, ch)) = v;
     }
   }
+  // head weights as register fragments.  Forward: the wave's own H tile is used straight from the
+  // accumulator registers as the B operand of a K = 32 product over its feature block (element j of
+  // lane half h of k-step s is feature 16s + 8(j>>2) + 4h + (j&3)), so A[m = k][that feature] is
+  // gathered to match; the four waves' partial sums meet in LDS.  Backward: A[m = in][k = out].
+  bf16x8 woF[2], woB;
   {
     const float *Wo = th + sp.w_off[NH];
-    for (int c = tid; c < 16 * 16; c += 256) {
-      const int row = c >> 4, ch = c & 15;   // row = head output k
-      bf16x8 v;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (bf16)(row < 2 ? Wo[(ch * 8 + j) * 2 + row] : 0.0f);
-      *reinterpret_cast<bf16x8 *>(lds + LY::WOT + img_off(row, ch)) = v;
-    }
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        woF[s2][j] = (bf16)(r < 2 ? Wo[(32 * w + 16 * s2 + 8 * (j >> 2) + 4 * h + (j & 3)) * 2 + r] : 0.0f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) woB[j] = (bf16)((h == 0 && j < 2) ? Wo[(32 * w + r) * 2 + j] : 0.0f);
+    if (tid < 4) reinterpret_cast<float *>(lds + LY::ZERO)[tid] = 0.0f;
   }
   // first-layer weights: one A fragment per wave, A[m = out 32w + r][k = in 8h + j], kept in registers
   bf16x8 w1frag;
@@ -202,111 +226,151 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
           for (int q = 0; q < RT; ++q) acc[q] = mfma_bf16(af[s], bfr[q][s], s == 0 ? bl : acc[q]);
       }
 #pragma unroll
-      for (int q = 0; q < RT; ++q)
-        store_tile_relu(lds + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + l * 8192, 32 * w, acc[q], lane);
+      for (int q = 0; q < RT; ++q) {
+        s16x4 pk[4];
+        store_tile_relu(lds + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + l * 8192, 32 * w, acc[q], lane, pk);
+        if (l == NH - 1) {   // head, this wave's 32 of the 128 features: partial (mu, log sigma) per row
+          f32x16 zero16, part;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) zero16[j] = 0.0f;
+          const bf16x8 b0 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(pk[0], pk[1], 0, 1, 2, 3, 4, 5, 6, 7));
+          const bf16x8 b1 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(pk[2], pk[3], 0, 1, 2, 3, 4, 5, 6, 7));
+          part = mfma_bf16(woF[0], b0, zero16);
+          part = mfma_bf16(woF[1], b1, part);
+          if (h == 0) {
+            const f32x2_t pv = {part[0], part[1]};
+            *reinterpret_cast<f32x2_t *>(lds + LY::PART + ((q * 4 + w) * 32 + r) * 8) = pv;
+          }
+        }
+      }
       __syncthreads();
     }
-    // ---- head (every wave computes it; wave 0 publishes d(out) into DZ[1]) ----------------------------
+    // ---- head + backward through it: every wave sums the partials and evaluates the likelihood for its
+    // lanes' rows; d(out) feeds dH straight from registers, and, transposed through a private 128-byte
+    // buffer (no workgroup barrier), the head weight gradient
     {
       f32x16 zero16;
 #pragma unroll
       for (int j = 0; j < 16; ++j) zero16[j] = 0.0f;
-      bf16x8 af[8], bfr[RT][8];
+      int offg[4];
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        af[s] = row_frag(lds + LY::WOT, r & 15, 2 * s + h);
+      for (int g = 0; g < 4; ++g) offg[g] = img_off(r, 4 * w + g) + 8 * h;
+      f32x2_t pr[RT][4], hm[RT][4];
+      bf16x8 ah[RT][2];
 #pragma unroll
-        for (int q = 0; q < RT; ++q)
-          bfr[q][s] = row_frag(lds + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + (NH - 1) * 8192, r, 2 * s + h);
+      for (int q = 0; q < RT; ++q) {
+        const char *Hin = lds + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + (NH - 1) * 8192;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) pr[q][ww] = *reinterpret_cast<const f32x2_t *>(lds + LY::PART + ((q * 4 + ww) * 32 + r) * 8);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) hm[q][g] = *reinterpret_cast<const f32x2_t *>(Hin + offg[g]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) ah[q][s] = tr_frag(Hin, 16 * s, 32 * w, lane);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < 8; ++s)
+      for (int q = 0; q < RT; ++q) {
+        const int row0 = 32 * (t * RT + q);
+        const float mu = ((pr[q][0][0] + pr[q][1][0]) + (pr[q][2][0] + pr[q][3][0])) + bo0;
+        const float sr = ((pr[q][0][1] + pr[q][1][1]) + (pr[q][2][1] + pr[q][3][1])) + bo1;
+        float dmu = 0.0f, dsg = 0.0f;
+        if (h == 0 && row0 + r < p.N) {
+          const float ll = row_loss_regr(mu, sr, yv[row0 + r], dmu, dsg);
+          ll_acc += ll;
+        }
+        bf16x8 bdo;
 #pragma unroll
-        for (int q = 0; q < RT; ++q) acc[q] = mfma_bf16(af[s], bfr[q][s], s == 0 ? zero16 : acc[q]);
-    }
-#pragma unroll
-    for (int q = 0; q < RT; ++q) {
-      char *DOimg = lds + LY::TILE + q * LY::TILE_BYTES + LY::DZ + 8192;
-      const int row0 = 32 * (t * RT + q);
-      float dmu = 0.0f, dsg = 0.0f;
-      if (h == 0 && row0 + r < p.N) {
-        const float ll = row_loss_regr(acc[q][0] + bo0, acc[q][1] + bo1, yv[row0 + r], dmu, dsg);
-        ll_acc += ll;
+        for (int j = 0; j < 8; ++j) bdo[j] = (bf16)0.0f;
+        bdo[0] = (bf16)dmu; bdo[1] = (bf16)dsg;          // lanes h = 1 and rows >= N carry zeros
+        acc[q] = mfma_bf16(woB, bdo, zero16);
+        char *dop = lds + LY::DOP + (w * RT + q) * 128;
+        if (h == 0) {
+          reinterpret_cast<bf16 *>(dop)[r] = bdo[0];
+          reinterpret_cast<bf16 *>(dop)[32 + r] = bdo[1];
+        }
       }
-      if (w == 0) {
-        bf16x8 c0, z8;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { c0[j] = (bf16)0.0f; z8[j] = (bf16)0.0f; }
-        c0[0] = (bf16)dmu; c0[1] = (bf16)dsg;
-        *reinterpret_cast<bf16x8 *>(DOimg + img_off(r, 2 * h)) = h == 0 ? c0 : z8;
-        *reinterpret_cast<bf16x8 *>(DOimg + img_off(r, 2 * h + 1)) = z8;
-      }
-    }
-    __syncthreads();
-    // ---- backward: head ---------------------------------------------------------------------------
-    {
-      f32x16 zero16;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) zero16[j] = 0.0f;
-      const bf16x8 a = tr_frag(lds + LY::WOT, 0, 32 * w, lane);
 #pragma unroll
       for (int q = 0; q < RT; ++q) {
         char *ts = lds + LY::TILE + q * LY::TILE_BYTES;
-        const char *Hin = ts + LY::HIMG + (NH - 1) * 8192, *DOimg = ts + LY::DZ + 8192;
-        acc[q] = mfma_bf16(a, row_frag(DOimg, r, h), zero16);
+        const char *dop = lds + LY::DOP + (w * RT + q) * 128;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          const bf16x8 bq = tr_frag(DOimg, 16 * s, 0, lane);
-          dWo = mfma_bf16(tr_frag(Hin, 16 * s, 32 * w, lane), bq, dWo);
+          const char *src = r < 2 ? dop + r * 64 + 32 * s + 16 * h : lds + LY::ZERO;
+          const bf16x8 bq = *reinterpret_cast<const bf16x8 *>(src);
+          dWo = mfma_bf16(ah[q][s], bq, dWo);
           dbo = bf16_colsum(bq, dbo);
         }
-        store_tile_masked(ts + LY::DZ, Hin, 32 * w, acc[q], lane);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4_t v = {acc[q][4 * g], acc[q][4 * g + 1], acc[q][4 * g + 2], acc[q][4 * g + 3]};
+          store_group_masked(ts + LY::DZ + offg[g], v, hm[q][g]);
+        }
       }
     }
     __syncthreads();
     // ---- backward: hidden layers NH .. 2 ------------------------------------------------------------
+    // Pinned order (sched_barrier fences): all dH operands are read first; the transposed dW operands
+    // are read between the dH MFMAs as those release registers; the dZ epilogue of the dH result runs
+    // between the dW MFMAs, which do not depend on it.
     int pp = 0;
 #pragma unroll
     for (int l = NH - 1; l >= 1; --l) {   // dZ of layer l is in DZ[pp]; its input is H_l (image l-1)
       const char *Wimg = lds + LY::WIMG + (l - 1) * 32768;
-      {
-        f32x16 zero16;
+      f32x16 zero16;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) zero16[j] = 0.0f;
-        bf16x8 af[8], bfr[RT][8];
+      for (int j = 0; j < 16; ++j) zero16[j] = 0.0f;
+      bf16x8 af[8], bfr[RT][8], bq[RT][2], ah[RT][2][4];
+      f32x2_t hm[RT][4];
+      int offg[4];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          af[s] = row_frag(Wimg, 32 * w + r, 2 * s + h);
+      for (int g = 0; g < 4; ++g) offg[g] = img_off(r, 4 * w + g) + 8 * h;
 #pragma unroll
-          for (int q = 0; q < RT; ++q)
-            bfr[q][s] = row_frag(lds + LY::TILE + q * LY::TILE_BYTES + LY::DZ + pp * 8192, r, 2 * s + h);
+      for (int s = 0; s < 8; ++s) {
+        af[s] = row_frag(Wimg, 32 * w + r, 2 * s + h);
+#pragma unroll
+        for (int q = 0; q < RT; ++q)
+          bfr[q][s] = row_frag(lds + LY::TILE + q * LY::TILE_BYTES + LY::DZ + pp * 8192, r, 2 * s + h);
+      }
+#pragma unroll
+      for (int q = 0; q < RT; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          hm[q][g] = *reinterpret_cast<const f32x2_t *>(lds + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + (l - 1) * 8192 + offg[g]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+#pragma unroll
+        for (int q = 0; q < RT; ++q) acc[q] = mfma_bf16(af[s], bfr[q][s], s == 0 ? zero16 : acc[q]);
+        {
+          const int q = (s * RT) / 8, sub = RT == 2 ? (s & 3) : (s >> 1);   // RT = 1: four steps carry reads
+          const char *ts = lds + LY::TILE + q * LY::TILE_BYTES;
+          const char *dz = ts + LY::DZ + pp * 8192, *Hin = ts + LY::HIMG + (l - 1) * 8192;
+          if (RT == 2 || (s & 1) == 0) {
+            if (sub == 0) { bq[q][0] = tr_frag(dz, 0, 32 * w, lane); ah[q][0][0] = tr_frag(Hin, 0, 0, lane); ah[q][0][1] = tr_frag(Hin, 0, 32, lane); }
+            if (sub == 1) { ah[q][0][2] = tr_frag(Hin, 0, 64, lane); ah[q][0][3] = tr_frag(Hin, 0, 96, lane); bq[q][1] = tr_frag(dz, 16, 32 * w, lane); }
+            if (sub == 2) { ah[q][1][0] = tr_frag(Hin, 16, 0, lane); ah[q][1][1] = tr_frag(Hin, 16, 32, lane); }
+            if (sub == 3) { ah[q][1][2] = tr_frag(Hin, 16, 64, lane); ah[q][1][3] = tr_frag(Hin, 16, 96, lane); }
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-          for (int q = 0; q < RT; ++q) acc[q] = mfma_bf16(af[s], bfr[q][s], s == 0 ? zero16 : acc[q]);
       }
 #pragma unroll
       for (int q = 0; q < RT; ++q) {
-        char *ts = lds + LY::TILE + q * LY::TILE_BYTES;
-        const char *dz = ts + LY::DZ + pp * 8192, *Hin = ts + LY::HIMG + (l - 1) * 8192;
-        bf16x8 bq[2], ah[2][4];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          bq[s] = tr_frag(dz, 16 * s, 32 * w, lane);
-#pragma unroll
-          for (int ib = 0; ib < 4; ++ib) ah[s][ib] = tr_frag(Hin, 16 * s, 32 * ib, lane);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        char *dzo = lds + LY::TILE + q * LY::TILE_BYTES + LY::DZ + (pp ^ 1) * 8192;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
-          for (int ib = 0; ib < 4; ++ib) dW[l - 1][ib] = mfma_bf16(ah[s][ib], bq[s], dW[l - 1][ib]);
-          db[l] = bf16_colsum(bq[s], db[l]);
+          for (int ib = 0; ib < 4; ++ib) {
+            dW[l - 1][ib] = mfma_bf16(ah[q][s][ib], bq[q][s], dW[l - 1][ib]);
+            if (ib & 1) {
+              const int g = 2 * s + (ib >> 1);
+              const f32x4_t v = {acc[q][4 * g], acc[q][4 * g + 1], acc[q][4 * g + 2], acc[q][4 * g + 3]};
+              store_group_masked(dzo + offg[g], v, hm[q][g]);
+            }
+          }
+          db[l] = bf16_colsum(bq[q][s], db[l]);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        store_tile_masked(ts + LY::DZ + (pp ^ 1) * 8192, Hin, 32 * w, acc[q], lane);
       }
       pp ^= 1;
       __syncthreads();
