@@ -123,9 +123,13 @@ class SamplerConfig:
     keep_warmup: bool = False
     prior_config: PriorConfig = field(default_factory=PriorConfig)
     partition_sampling: bool = False
+    # extension (not in the reference schema, optional): which grad kernel the HIP sampler uses.
+    # 'auto' = fastest fp32 kernel; 'mfma_w128_bf16' = bf16 matrix operands (BASELINE config 3)
+    grad_kernel: str = 'auto'
 
     def __post_init__(self):
         _check(self.name in ('nuts', 'mclmc', 'hmc', 'mclmc_hip'), f'unknown sampler {self.name!r}')
+        _check(self.grad_kernel in ('auto', 'generic', 'mfma_w64', 'mfma_w128_bf16'), f'unknown grad_kernel {self.grad_kernel!r}')
 
     @property
     def prior(self) -> Prior:

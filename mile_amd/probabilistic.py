@@ -20,7 +20,8 @@ TASK_ALIASES = {'regr': 'regr', 'regression': 'regr', 'class': 'classification',
 class ProbabilisticModel:
     """src/training/probabilistic.py:16-138."""
 
-    def __init__(self, module, params=None, prior: Prior | None = None, task: str = 'regr', n_batches: int = 1):
+    def __init__(self, module, params=None, prior: Prior | None = None, task: str = 'regr', n_batches: int = 1,
+                 grad_kernel: str = 'auto'):
         """``module``: anything with in_features / hidden_structure / activation (an FCNConfig
         plus the feature count, or a ModelSpec)."""
         prior = prior or Prior.from_name('StandardNormal')
@@ -41,6 +42,7 @@ class ProbabilisticModel:
         self.n_params = self.spec.n_params
         self.n_batches = n_batches
         self.prior = prior
+        self.grad_kernel = grad_kernel   # 'auto' | 'generic' | 'mfma_w64' | 'mfma_w128_bf16' (extension)
         self._engines: dict = {}
 
     def __str__(self):
@@ -58,7 +60,7 @@ class ProbabilisticModel:
         dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
         key = (id(x), id(y), str(dev))
         if key not in self._engines:
-            self._engines[key] = (Engine(self.spec, x, y, device=dev), x, y)   # keep x, y alive: id() stays unique
+            self._engines[key] = (Engine(self.spec, x, y, device=dev, grad_kernel=self.grad_kernel), x, y)   # keep x, y alive: id() stays unique
         return self._engines[key][0]
 
     def log_prior(self, params) -> torch.Tensor:

@@ -63,7 +63,8 @@ class BDETrainer:
                                     activation=config.model.activation,
                                     task='regr' if config.data.task == 'regr' else 'classification')
         self.prob_model = ProbabilisticModel(module=self.spec_model, prior=config.training.sampler.prior,
-                                             task=config.data.task, n_batches=1)
+                                             task=config.data.task, n_batches=1,
+                                             grad_kernel=config.training.sampler.grad_kernel)
         self.exp_dir = self.config.experiment_dir
         if self.rank == 0:
             save_tree(self.exp_dir, self.prob_model.spec)

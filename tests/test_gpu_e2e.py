@@ -330,6 +330,31 @@ def test_lppd_matches_oracle_after_equal_step_count(oracle):
     assert abs(got - o_lppd) < 0.01 * abs(o_lppd), (got, o_lppd)
 
 
+def test_bf16_kernel_lppd_within_one_percent_of_fp32(oracle):
+    """BASELINE config 3 runs with bf16 matrix operands: the +-1 % LPPD gate for that kernel, against the
+    fp32 kernel (itself checked against the oracle above) after the same number of steps from the same
+    state with the same noise.  Trajectories decorrelate under the 1e-2 gradient perturbation, so this is a
+    statement about the sampled predictive, not a bitwise one."""
+    from mile_amd.metrics import lppd, pointwise_lppd, predict
+    ospec = oracle.ModelSpec(9, (128, 128, 128, 2))
+    E, T, N = 32, 200, 600
+    prob = oracle.synthetic_problem(ospec, N, E, seed=5)
+    rng = np.random.default_rng(2)
+    Xt = rng.standard_normal((150, 9)).astype(np.float32)
+    yt = rng.standard_normal(150).astype(np.float32)
+    got = {}
+    for k in ('generic', 'mfma_w128_bf16'):
+        eng = _engine(ospec, prob['X'], prob['y'], k)
+        assert eng.grad_kernel == k
+        s = eng.init(torch.from_numpy(prob['theta0']), seed=11)
+        s, info, kept = eng.step(s, torch.from_numpy(prob['eps']), torch.from_numpy(prob['L']), n_steps=T, seed=12,
+                                 n_thinning=5)
+        assert torch.isfinite(s.position).all() and torch.isfinite(info.energy_change).all()
+        out = predict(_spec(ospec), kept.permute(1, 0, 2), torch.from_numpy(Xt).cuda())
+        got[k] = lppd(pointwise_lppd(out, torch.from_numpy(yt), 'regr')).item()
+    assert abs(got['mfma_w128_bf16'] - got['generic']) < 0.01 * abs(got['generic']), got
+
+
 @pytest.mark.parametrize('F,hs,act,task,kernels', [
     (5, (64, 64, 64, 2), 'relu', 'regr', ('mfma_w64', 'generic')),
     (5, (64, 2), 'relu', 'regr', ('mfma_w64', 'generic')),
