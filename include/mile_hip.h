@@ -63,7 +63,8 @@ typedef enum mile_grad_kernel {
   MILE_GRAD_AUTO = 0,
   MILE_GRAD_GENERIC = 1,          /* any FCN, fp32 VALU */
   MILE_GRAD_MFMA_W64 = 2,         /* ReLU regression, 1-3 hidden layers of width 64, fp32 MFMA */
-  MILE_GRAD_MFMA_W128_BF16 = 3    /* ReLU regression, 1-3 hidden layers of width 128, bf16 MFMA */
+  MILE_GRAD_MFMA_W128_BF16 = 3,   /* ReLU regression, 1-3 hidden layers of width 128, bf16 MFMA */
+  MILE_GRAD_GEMM_F32 = 4          /* any FCN, fp32: rocBLAS strided-batched SGEMMs + elementwise HIP kernels (wide nets) */
 } mile_grad_kernel;
 
 /* FCNConfig (src/config/models/fcn.py:7-30) + PriorConfig (src/config/sampler.py:60-95)

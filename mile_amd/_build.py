@@ -14,7 +14,7 @@ CSRC = PKG_DIR / 'csrc'
 LIB_PATH = PKG_DIR / 'libmile_hip.so'
 SOURCES = ['mile_hip.hip']
 HEADERS = ['mile_device.h', 'mile_grad_generic.h', 'mile_grad_w64.h', 'mile_grad_w64_block.inc', 'mile_bf16_frag.h',
-           'mile_grad_w128b.h', 'mile_predict.h', 'mile_update.h']
+           'mile_grad_w128b.h', 'mile_grad_gemm.h', 'mile_predict.h', 'mile_update.h']
 
 
 def _hipcc() -> str:
@@ -37,7 +37,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     if not force and not needs_build():
         return LIB_PATH
     cmd = [_hipcc(), '-O3', '--offload-arch=gfx950', '-std=c++17', '-shared', '-fPIC',
-           '-o', str(LIB_PATH)] + [str(CSRC / f) for f in SOURCES]
+           '-o', str(LIB_PATH)] + [str(CSRC / f) for f in SOURCES] + ['-ldl']
     if verbose:
         print(' '.join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)

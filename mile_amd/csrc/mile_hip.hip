@@ -10,10 +10,13 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include "mile_device.h"
 #include "mile_grad_generic.h"
 #include "mile_grad_w64.h"
 #include "mile_grad_w128b.h"
+#include "mile_grad_gemm.h"
 #include "mile_predict.h"
 #include "mile_update.h"
 
@@ -44,6 +47,11 @@ struct mile_sampler {
   float *ev_X = nullptr, *ev_Xp = nullptr; void *ev_y = nullptr; int ev_cap = 0;   // evaluation (test) set staging
   float *alt_x = nullptr, *alt_u = nullptr, *alt_g = nullptr, *alt_logp = nullptr;   // ping-pong state of mile_tune
   int grad_kernel = MILE_GRAD_AUTO;
+  // layer-wise GEMM path (MILE_GRAD_GEMM_F32): rocBLAS handle and activation workspace
+  void *blas = nullptr;
+  float *gemm_ws = nullptr;
+  size_t gemm_ws_floats = 0;
+  int gemm_R = 0, gemm_E = 0;
   // timing of grad launches
   bool timing = false;
   std::vector<hipEvent_t> ev;
@@ -61,6 +69,45 @@ static bool w64_supported(const mile_model_spec &sp) {
   return true;
 }
 
+// ---- rocBLAS, resolved at first use: libmile_hip.so has no link-time dependency on it -----------
+typedef int (*rb_create_t)(void **);
+typedef int (*rb_destroy_t)(void *);
+typedef int (*rb_set_stream_t)(void *, hipStream_t);
+typedef int (*rb_sgemm_sb_t)(void *, int, int, int, int, int, const float *, const float *, int, long long, const float *, int,
+                             long long, const float *, float *, int, long long, int);
+static struct {
+  void *lib = nullptr;
+  rb_create_t create = nullptr;
+  rb_destroy_t destroy = nullptr;
+  rb_set_stream_t set_stream = nullptr;
+  rb_sgemm_sb_t sgemm_sb = nullptr;
+  bool tried = false;
+} g_rb;
+enum { RB_OP_N = 111, RB_OP_T = 112 };   // rocblas_operation_none / _transpose
+
+static bool rocblas_load() {
+  if (g_rb.tried) return g_rb.sgemm_sb != nullptr;
+  g_rb.tried = true;
+  for (const char *name : {"librocblas.so.5", "librocblas.so", "/opt/rocm/lib/librocblas.so"}) {
+    g_rb.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (g_rb.lib) break;
+  }
+  if (!g_rb.lib) return false;
+  g_rb.create = (rb_create_t)dlsym(g_rb.lib, "rocblas_create_handle");
+  g_rb.destroy = (rb_destroy_t)dlsym(g_rb.lib, "rocblas_destroy_handle");
+  g_rb.set_stream = (rb_set_stream_t)dlsym(g_rb.lib, "rocblas_set_stream");
+  g_rb.sgemm_sb = (rb_sgemm_sb_t)dlsym(g_rb.lib, "rocblas_sgemm_strided_batched");
+  if (!g_rb.create || !g_rb.destroy || !g_rb.set_stream || !g_rb.sgemm_sb) { g_rb.sgemm_sb = nullptr; return false; }
+  return true;
+}
+
+// library GEMMs pay off once the hidden layers are wide; below that the single-launch generic kernel wins
+static bool gemm_preferred(const mile_model_spec &sp) {
+  int mw = 0;
+  for (int l = 0; l + 1 < sp.n_layers; ++l) mw = std::max(mw, sp.widths[l]);
+  return sp.n_layers >= 2 && mw >= 96;
+}
+
 static bool w128b_supported(const mile_model_spec &sp) {
   if (sp.task != MILE_TASK_REGRESSION || sp.activation != MILE_ACT_RELU) return false;
   const int nh = sp.n_layers - 1;
@@ -73,7 +120,10 @@ static bool w128b_supported(const mile_model_spec &sp) {
 }
 
 static int resolved_kernel(const mile_sampler *s) {
-  if (s->grad_kernel == MILE_GRAD_AUTO) return w64_supported(s->spec) ? MILE_GRAD_MFMA_W64 : MILE_GRAD_GENERIC;
+  if (s->grad_kernel == MILE_GRAD_AUTO) {
+    if (w64_supported(s->spec)) return MILE_GRAD_MFMA_W64;
+    return gemm_preferred(s->spec) && rocblas_load() ? MILE_GRAD_GEMM_F32 : MILE_GRAD_GENERIC;
+  }
   return s->grad_kernel;
 }
 
@@ -92,6 +142,7 @@ static int choose_S(const mile_sampler *s, int E, int kernel) {
     S = std::min(S, std::max(1, NB / 4));  // keep >= 4 row blocks (one per wave) per workgroup
     return S;
   }
+  if (kernel == MILE_GRAD_GEMM_F32) return 1;
   if (kernel == MILE_GRAD_MFMA_W128_BF16) {
     const int NBS = s->Npb / 64;              // iterations of two 32-row tiles
     int S = std::max(1, s->n_cu / std::max(E, 1));
@@ -198,6 +249,8 @@ int32_t mile_destroy(mile_sampler *s) {
   if (s->ev_y) (void)hipFree(s->ev_y);
   free_data(s);
   free_ws(s);
+  if (s->gemm_ws) (void)hipFree(s->gemm_ws);
+  if (s->blas && g_rb.destroy) (void)g_rb.destroy(s->blas);
   for (auto ev : s->ev) (void)hipEventDestroy(ev);
   delete s;
   return MILE_OK;
@@ -283,7 +336,8 @@ int32_t mile_reserve(mile_sampler *s, int32_t E) {
 
 int32_t mile_set_grad_kernel(mile_sampler *s, int32_t which) {
   if (!s) return fail(MILE_ERR_INVALID, "null handle");
-  if (which < MILE_GRAD_AUTO || which > MILE_GRAD_MFMA_W128_BF16) return fail(MILE_ERR_INVALID, "unknown grad kernel");
+  if (which < MILE_GRAD_AUTO || which > MILE_GRAD_GEMM_F32) return fail(MILE_ERR_INVALID, "unknown grad kernel");
+  if (which == MILE_GRAD_GEMM_F32 && !rocblas_load()) return fail(MILE_ERR_HIP, "GEMM_F32 needs librocblas.so, which could not be loaded");
   if (which == MILE_GRAD_MFMA_W128_BF16 && !w128b_supported(s->spec))
     return fail(MILE_ERR_INVALID, "MFMA_W128_BF16 needs ReLU regression with 1-3 hidden layers of width 128 and F <= 16");
   if (which == MILE_GRAD_MFMA_W64 && !w64_supported(s->spec))
@@ -366,6 +420,92 @@ static hipError_t launch_w128b(const GradParams &gp, int E, hipStream_t st) {
 template <int NH, int FQ>
 static int w64_lds_bytes() { return W64Layout<NH, FQ>::BYTES; }
 
+// Layer-wise path: per row chunk, forward GEMM + bias/activation per layer, head, then per layer
+// dW (accumulated in place in the slab), bias column sums, dH GEMM + activation derivative.
+// Row-major products through rocBLAS's column-major interface: C = A B  <=>  C^T = B^T A^T.
+static int launch_grad_gemm(mile_sampler *s, const GradParams &gp, int E, hipStream_t st) {
+  if (!rocblas_load()) return fail(MILE_ERR_HIP, "librocblas.so could not be loaded");
+  const DevSpec &ds = s->ds;
+  const int L = ds.n_layers, F = ds.in_features, d = ds.d, N = s->N;
+  if (!s->blas) {
+    if (g_rb.create(&s->blas) != 0) { s->blas = nullptr; return fail(MILE_ERR_HIP, "rocblas_create_handle failed"); }
+  }
+  if (g_rb.set_stream(s->blas, st) != 0) return fail(MILE_ERR_HIP, "rocblas_set_stream failed");
+  size_t per_row = 2 * (size_t)ds.max_width;
+  for (int l = 0; l < L; ++l) per_row += ds.widths[l];
+  if (E != s->gemm_E || !s->gemm_ws) {   // (re)size the activation workspace: <= ~4 GiB, whole data set if it fits
+    const size_t budget = (size_t)1 << 30;   // floats
+    size_t R = budget / ((size_t)E * per_row);
+    R = std::min<size_t>(R, (size_t)N);
+    if (R < (size_t)N) R = std::max<size_t>(256, R / 256 * 256);
+    R = std::min<size_t>(R, (size_t)N);
+    if (const char *rv = getenv("MILE_GEMM_ROWS")) R = std::max<size_t>(1, std::min<size_t>((size_t)atoll(rv), (size_t)N));   // test hook
+    const size_t need = (size_t)E * R * per_row;
+    if (need > s->gemm_ws_floats) {
+      if (s->gemm_ws) (void)hipFree(s->gemm_ws);
+      s->gemm_ws = nullptr; s->gemm_ws_floats = 0;
+      HIP_TRY(hipMalloc(&s->gemm_ws, need * 4));
+      s->gemm_ws_floats = need;
+    }
+    s->gemm_R = (int)R; s->gemm_E = E;
+  }
+  const int R = s->gemm_R;
+  float *H[MILE_MAX_LAYERS], *tmp[2];
+  {
+    float *q = s->gemm_ws;
+    for (int l = 0; l < L; ++l) { H[l] = q; q += (size_t)E * R * ds.widths[l]; }
+    tmp[0] = q; q += (size_t)E * R * ds.max_width;
+    tmp[1] = q;
+  }
+  const float one = 1.0f, zero = 0.0f;
+  float *slab = gp.slabs;        // S = 1: [E][dp]
+  const long long dp = gp.dp;
+  auto gemm = [&](int ta, int tb, int m, int n, int k, const float *A, int lda, long long sa, const float *B, int ldb, long long sb,
+                  const float *beta, float *C, int ldc, long long sc) -> int {
+    return g_rb.sgemm_sb(s->blas, ta, tb, m, n, k, &one, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, E);
+  };
+  auto blocks = [](long long n) { return (unsigned)std::min<long long>((n + 255) / 256, 4096); };
+  for (int r0 = 0, chunk = 0; r0 < N; r0 += R, ++chunk) {
+    const int Rc = std::min(R, N - r0);
+    // ---- forward
+    for (int l = 0; l < L; ++l) {
+      const int fin = l == 0 ? F : ds.widths[l - 1], fout = ds.widths[l];
+      const float *in = l == 0 ? gp.X + (size_t)r0 * F : H[l - 1];
+      const long long sin = l == 0 ? 0 : (long long)Rc * fin;
+      if (gemm(RB_OP_N, RB_OP_N, fout, Rc, fin, gp.theta + ds.w_off[l], fout, d, in, fin, sin, &zero, H[l], fout, (long long)Rc * fout))
+        return fail(MILE_ERR_HIP, "rocblas sgemm (forward) failed");
+      const long long RW = (long long)Rc * fout;
+      k_gemm_bias_act<<<dim3(blocks(RW), E), 256, 0, st>>>(H[l], gp.theta, ds.b_off[l], d, fout, RW, ds.activation, l + 1 < L);
+    }
+    // ---- head: log-likelihood and d(out), in place
+    k_gemm_head<<<E, 256, 0, st>>>(H[L - 1], gp.y, r0, Rc, ds.widths[L - 1], ds.task, gp.llpart, chunk == 0);
+    // ---- backward
+    float *dz = H[L - 1];
+    int pp = 0;
+    const float *beta = chunk == 0 ? &zero : &one;
+    for (int l = L - 1; l >= 0; --l) {
+      const int fin = l == 0 ? F : ds.widths[l - 1], fout = ds.widths[l];
+      const float *in = l == 0 ? gp.X + (size_t)r0 * F : H[l - 1];
+      const long long sin = l == 0 ? 0 : (long long)Rc * fin;
+      // dW[in][out] (+)= in^T dz, written straight into the slab at the kernel's offset
+      if (gemm(RB_OP_N, RB_OP_T, fout, fin, Rc, dz, fout, (long long)Rc * fout, in, fin, sin, beta, slab + ds.w_off[l], fout, dp))
+        return fail(MILE_ERR_HIP, "rocblas sgemm (dW) failed");
+      k_gemm_colsum<<<dim3((fout + 63) / 64, E), 256, 0, st>>>(dz, Rc, fout, slab + ds.b_off[l], dp, chunk != 0);
+      if (l > 0) {
+        if (gemm(RB_OP_T, RB_OP_N, fin, Rc, fout, gp.theta + ds.w_off[l], fout, d, dz, fout, (long long)Rc * fout, &zero, tmp[pp], fin,
+                 (long long)Rc * fin))
+          return fail(MILE_ERR_HIP, "rocblas sgemm (dH) failed");
+        const long long RW = (long long)Rc * fin;
+        k_gemm_act_grad<<<dim3(blocks(RW), E), 256, 0, st>>>(tmp[pp], H[l - 1], RW, ds.activation);
+        dz = tmp[pp];
+        pp ^= 1;
+      }
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return MILE_OK;
+}
+
 static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t st) {
   if (!s->X) return fail(MILE_ERR_STATE, "no data: call mile_set_data first");
   const int kernel = resolved_kernel(s);
@@ -401,6 +541,9 @@ static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t s
     else if (nh == 2 && fq == 2) e = launch_w64<2, 2>(gp, E, st);
     else if (nh == 3 && fq == 2) e = launch_w64<3, 2>(gp, E, st);
     HIP_TRY(e);
+  } else if (kernel == MILE_GRAD_GEMM_F32) {
+    const int rc = launch_grad_gemm(s, gp, E, st);
+    if (rc) return rc;
   } else if (kernel == MILE_GRAD_MFMA_W128_BF16) {
     if (!s->Xb) return fail(MILE_ERR_STATE, "bf16 data copies missing: call mile_set_data");
     const int nh = s->spec.n_layers - 1;
@@ -496,6 +639,9 @@ int32_t mile_grad_launch_info(const mile_sampler *s, int32_t E, int32_t *grid_x,
     lds = nh == 1 ? (fq == 1 ? w64_lds_bytes<1, 1>() : w64_lds_bytes<1, 2>())
         : nh == 2 ? (fq == 1 ? w64_lds_bytes<2, 1>() : w64_lds_bytes<2, 2>())
                   : (fq == 1 ? w64_lds_bytes<3, 1>() : w64_lds_bytes<3, 2>());
+  } else if (kernel == MILE_GRAD_GEMM_F32) {
+    nm = "rocblas_sgemm_strided_batched+k_gemm_*";
+    lds = 0;
   } else if (kernel == MILE_GRAD_MFMA_W128_BF16) {
     const int nh = s->spec.n_layers - 1;
     nm = "k_grad_w128b";

@@ -28,12 +28,15 @@ CASES = [
     # in_features, hidden, activation, task, prior, N, E, kernels
     (5, (64, 64, 64, 2), 'relu', 'regr', 'Normal', 1052, 16, ('generic', 'mfma_w64')),
     (5, (64, 64, 64, 2), 'relu', 'regr', 'Normal', 100, 3, ('generic', 'mfma_w64')),
-    (5, (64, 64, 2), 'relu', 'regr', 'Normal', 333, 5, ('generic', 'mfma_w64')),
+    (5, (64, 64, 2), 'relu', 'regr', 'Normal', 333, 5, ('generic', 'mfma_w64', 'gemm_f32')),
     (8, (64, 2), 'relu', 'regr', 'Laplace', 64, 2, ('generic', 'mfma_w64')),
     (5, (16, 16, 2), 'relu', 'regr', 'Normal', 1052, 12, ('generic',)),
-    (9, (24, 17, 2), 'tanh', 'regr', 'Normal', 257, 4, ('generic',)),
-    (11, (32, 7), 'sigmoid', 'classification', 'Normal', 500, 6, ('generic',)),
-    (54, (40, 40, 7), 'relu', 'classification', 'Laplace', 130, 3, ('generic',)),
+    (9, (24, 17, 2), 'tanh', 'regr', 'Normal', 257, 4, ('generic', 'gemm_f32')),
+    (11, (32, 7), 'sigmoid', 'classification', 'Normal', 500, 6, ('generic', 'gemm_f32')),
+    (54, (40, 40, 7), 'relu', 'classification', 'Laplace', 130, 3, ('generic', 'gemm_f32')),
+    # wide nets: the layer-wise rocBLAS path (what AUTO picks there), B3- and B4-shaped
+    (9, (128, 128, 128, 2), 'relu', 'regr', 'Normal', 700, 6, ('gemm_f32', 'auto')),
+    (54, (256, 256, 256, 256, 7), 'relu', 'classification', 'Normal', 300, 3, ('gemm_f32', 'generic')),
     # edge cases: one particle, fewer rows than one MFMA block, ragged last block, one hidden layer,
     # more workgroups than row blocks, F at the padding boundary
     (5, (64, 64, 64, 2), 'relu', 'regr', 'Normal', 2, 1, ('generic', 'mfma_w64')),
@@ -56,7 +59,7 @@ def test_logpost_grad_matches_oracle(oracle, F, hs, act, task, prior, N, E, kern
     lp_ref, g_ref = oracle.logpost_and_grad(ospec, prob['theta0'].astype(np.float64), prob['X'], prob['y'])
     for k in kernels:
         eng = _engine(oracle, ospec, prob, k)
-        assert eng.grad_kernel == k
+        assert eng.grad_kernel == (k if k != 'auto' else 'gemm_f32')
         lp, g = eng.logpost_grad(torch.from_numpy(prob['theta0']))
         torch.cuda.synchronize()
         # fp32 accumulation over N rows vs fp64: tolerance 2e-5 relative to the largest entry
@@ -108,6 +111,19 @@ def test_bf16_w128_grad_matches_oracle(oracle, F, hs, N, E):
     assert off == ospec.n_params
     tot = np.linalg.norm(g - g_full, axis=1) / np.linalg.norm(g_full, axis=1)
     assert tot.max() < 5e-2, tot.max()
+
+
+def test_gemm_path_row_chunks_accumulate(oracle, monkeypatch):
+    """The layer-wise path walks the data in row chunks when the activation workspace would not hold all of
+    it; force 3 ragged chunks and compare with the oracle."""
+    monkeypatch.setenv('MILE_GEMM_ROWS', '100')
+    ospec = oracle.ModelSpec(7, (96, 50, 2), activation='tanh')
+    prob = oracle.synthetic_problem(ospec, 257, 4, seed=8)
+    lp_ref, g_ref = oracle.logpost_and_grad(ospec, prob['theta0'].astype(np.float64), prob['X'], prob['y'])
+    eng = _engine(oracle, ospec, prob, 'gemm_f32')
+    lp, g = eng.logpost_grad(torch.from_numpy(prob['theta0']))
+    assert _relerr(lp.cpu().numpy(), lp_ref) < 2e-5
+    assert _relerr(g.cpu().numpy(), g_ref) < 2e-5
 
 
 def test_philox_noise_bits_match_oracle(oracle):
