@@ -84,3 +84,29 @@ __global__ __launch_bounds__(256) void k_gemm_colsum(const float *dZ, int R, int
     *p = accumulate ? *p + t : t;
   }
 }
+
+// Evaluation: per-row log-likelihood of the head outputs (no nansum zeroing: src/inference/metrics.py:247-294
+// uses the distributions' log_prob directly).  out_ll[(s0 + s) * N + r0 + r].
+__global__ __launch_bounds__(256) void k_gemm_rowll(const float *out, const void *y, long long r0, int R, int K, int task, float *out_ll,
+                                                    long long N, long long s0) {
+  const int s = blockIdx.y;
+  const float *o = out + (size_t)s * R * K;
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < R; r += gridDim.x * 256) {
+    const float *z = o + (size_t)r * K;
+    float v;
+    if (task == MILE_TASK_REGRESSION) {
+      const float es = expf(z[1]);
+      const float sig = isnan(es) ? es : fminf(fmaxf(es, 1e-6f), 1e6f);
+      const float rr = (((const float *)y)[r0 + r] - z[0]) / sig;
+      v = -0.5f * rr * rr - logf(sig) - 0.91893853320467274f;
+    } else {
+      const int yi = ((const int32_t *)y)[r0 + r];
+      float m = z[0];
+      for (int c = 1; c < K; ++c) m = fmaxf(m, z[c]);
+      float se = 0.0f;
+      for (int c = 0; c < K; ++c) se += expf(z[c] - m);
+      v = z[yi] - (m + logf(se));
+    }
+    out_ll[(size_t)(s0 + s) * N + r0 + r] = v;
+  }
+}

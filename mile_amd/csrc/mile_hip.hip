@@ -574,6 +574,55 @@ static hipError_t launch_fwd_w64(const PredParams &pp, int S, hipStream_t st) {
   return hipGetLastError();
 }
 
+// Evaluation forward for wide nets: the same strided-batched SGEMMs, samples as the batch.
+static int launch_fwd_gemm(mile_sampler *s, const float *theta, int S, const float *X, const void *y, int N, float *out, hipStream_t st) {
+  if (!rocblas_load()) return fail(MILE_ERR_HIP, "librocblas.so could not be loaded");
+  const DevSpec &ds = s->ds;
+  const int L = ds.n_layers, F = ds.in_features, d = ds.d;
+  if (!s->blas && g_rb.create(&s->blas) != 0) { s->blas = nullptr; return fail(MILE_ERR_HIP, "rocblas_create_handle failed"); }
+  if (g_rb.set_stream(s->blas, st) != 0) return fail(MILE_ERR_HIP, "rocblas_set_stream failed");
+  // two ping-pong activation buffers of [Sc][Rc][max_width]; <= 1 GiB of floats
+  const size_t budget = (size_t)1 << 28;
+  const int Sc = std::min(S, 1024);
+  size_t Rr = budget / (2 * (size_t)Sc * ds.max_width);
+  Rr = std::max<size_t>(1, std::min<size_t>(Rr, (size_t)N));
+  if (const char *rv = getenv("MILE_GEMM_ROWS")) Rr = std::max<size_t>(1, std::min<size_t>((size_t)atoll(rv), (size_t)N));
+  const int R = (int)Rr;
+  const size_t need = 2 * (size_t)Sc * R * ds.max_width;
+  if (need > s->gemm_ws_floats) {
+    if (s->gemm_ws) (void)hipFree(s->gemm_ws);
+    s->gemm_ws = nullptr; s->gemm_ws_floats = 0; s->gemm_E = 0;
+    HIP_TRY(hipMalloc(&s->gemm_ws, need * 4));
+    s->gemm_ws_floats = need;
+  }
+  s->gemm_E = 0;   // the gradient path re-derives its layout on its next call
+  float *buf[2] = {s->gemm_ws, s->gemm_ws + (size_t)Sc * R * ds.max_width};
+  const float one = 1.0f, zero = 0.0f;
+  for (int s0 = 0; s0 < S; s0 += Sc) {
+    const int Sn = std::min(Sc, S - s0);
+    const float *th = theta + (size_t)s0 * d;
+    for (int r0 = 0; r0 < N; r0 += R) {
+      const int Rc = std::min(R, N - r0);
+      int pp = 0;
+      for (int l = 0; l < L; ++l) {
+        const int fin = l == 0 ? F : ds.widths[l - 1], fout = ds.widths[l];
+        const float *in = l == 0 ? X + (size_t)r0 * F : buf[pp ^ 1];
+        const long long sin = l == 0 ? 0 : (long long)Rc * fin;
+        if (g_rb.sgemm_sb(s->blas, RB_OP_N, RB_OP_N, fout, Rc, fin, &one, th + ds.w_off[l], fout, d, in, fin, sin, &zero, buf[pp], fout,
+                          (long long)Rc * fout, Sn))
+          return fail(MILE_ERR_HIP, "rocblas sgemm (evaluation) failed");
+        const long long RW = (long long)Rc * fout;
+        k_gemm_bias_act<<<dim3((unsigned)std::min<long long>((RW + 255) / 256, 4096), Sn), 256, 0, st>>>(buf[pp], th, ds.b_off[l], d, fout, RW,
+                                                                                                   ds.activation, l + 1 < L);
+        pp ^= 1;
+      }
+      k_gemm_rowll<<<dim3((Rc + 255) / 256, Sn), 256, 0, st>>>(buf[pp ^ 1], y, r0, Rc, ds.widths[L - 1], ds.task, out, N, s0);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return MILE_OK;
+}
+
 extern "C" int32_t mile_pointwise_loglik(mile_sampler *s, const float *theta, int32_t S, const float *X, const void *y,
                                          int64_t N, float *out, void *stream) {
   if (!s || !theta || !X || !y || !out || S < 1) return fail(MILE_ERR_INVALID, "mile_pointwise_loglik: bad argument");
@@ -600,6 +649,10 @@ extern "C" int32_t mile_pointwise_loglik(mile_sampler *s, const float *theta, in
   pp.spec = s->ds; pp.theta = theta; pp.X = s->ev_X; pp.Xp = s->ev_Xp; pp.y = s->ev_y; pp.out = out;
   pp.N = (int)N; pp.Npad = Npad; pp.Fp = Fp; pp.R = generic_R(s->ds);
   const int kernel = resolved_kernel(s);
+  if (kernel == MILE_GRAD_GEMM_F32 || (kernel == MILE_GRAD_MFMA_W128_BF16 && rocblas_load())) {
+    // wide nets: evaluation stays fp32 whatever the sampling kernel was
+    return launch_fwd_gemm(s, theta, S, s->ev_X, s->ev_y, (int)N, out, st);
+  }
   if (kernel == MILE_GRAD_MFMA_W64) {
     const int NB = Npad / 32;
     pp.SB = std::max(1, std::min(std::max(1, (2 * s->n_cu) / S), std::max(1, NB / 4)));

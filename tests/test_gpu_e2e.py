@@ -359,7 +359,10 @@ def test_bf16_kernel_lppd_within_one_percent_of_fp32(oracle):
     (5, (64, 64, 64, 2), 'relu', 'regr', ('mfma_w64', 'generic')),
     (5, (64, 2), 'relu', 'regr', ('mfma_w64', 'generic')),
     (9, (24, 17, 2), 'tanh', 'regr', ('generic',)),
-    (11, (32, 7), 'sigmoid', 'classification', ('generic',)),
+    (11, (32, 7), 'sigmoid', 'classification', ('generic', 'gemm_f32')),
+    # wide nets evaluate through the strided-batched SGEMM forward (fp32 also when sampling ran on bf16 operands)
+    (9, (128, 128, 128, 2), 'relu', 'regr', ('gemm_f32', 'mfma_w128_bf16')),
+    (54, (256, 256, 7), 'tanh', 'classification', ('gemm_f32',)),
 ])
 def test_pointwise_loglik_kernel_matches_oracle(oracle, F, hs, act, task, kernels):
     from mile_amd.metrics import lppd
