@@ -49,7 +49,8 @@ struct mile_sampler {
   int grad_kernel = MILE_GRAD_AUTO;
   // layer-wise GEMM path (MILE_GRAD_GEMM_F32): rocBLAS handle and activation workspace
   void *blas = nullptr;
-  float *gemm_ws = nullptr;
+  float *gemm_ws = nullptr, *gemm_ones = nullptr;
+  int gemm_ones_n = 0;
   size_t gemm_ws_floats = 0;
   int gemm_R = 0, gemm_E = 0;
   // timing of grad launches
@@ -250,6 +251,7 @@ int32_t mile_destroy(mile_sampler *s) {
   free_data(s);
   free_ws(s);
   if (s->gemm_ws) (void)hipFree(s->gemm_ws);
+  if (s->gemm_ones) (void)hipFree(s->gemm_ones);
   if (s->blas && g_rb.destroy) (void)g_rb.destroy(s->blas);
   for (auto ev : s->ev) (void)hipEventDestroy(ev);
   delete s;
@@ -420,6 +422,11 @@ static hipError_t launch_w128b(const GradParams &gp, int E, hipStream_t st) {
 template <int NH, int FQ>
 static int w64_lds_bytes() { return W64Layout<NH, FQ>::BYTES; }
 
+__global__ void k_fill(float *p, float v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
 // Layer-wise path: per row chunk, forward GEMM + bias/activation per layer, head, then per layer
 // dW (accumulated in place in the slab), bias column sums, dH GEMM + activation derivative.
 // Row-major products through rocBLAS's column-major interface: C = A B  <=>  C^T = B^T A^T.
@@ -450,6 +457,13 @@ static int launch_grad_gemm(mile_sampler *s, const GradParams &gp, int E, hipStr
     s->gemm_R = (int)R; s->gemm_E = E;
   }
   const int R = s->gemm_R;
+  if (s->gemm_ones_n < R) {   // ones[R]: bias gradients are dZ^T 1 (a skinny GEMM, memory bound like the sum it replaces)
+    if (s->gemm_ones) (void)hipFree(s->gemm_ones);
+    s->gemm_ones = nullptr; s->gemm_ones_n = 0;
+    HIP_TRY(hipMalloc(&s->gemm_ones, (size_t)R * 4));
+    k_fill<<<(R + 255) / 256, 256, 0, st>>>(s->gemm_ones, 1.0f, R);
+    s->gemm_ones_n = R;
+  }
   float *H[MILE_MAX_LAYERS], *tmp[2];
   {
     float *q = s->gemm_ws;
@@ -490,7 +504,8 @@ static int launch_grad_gemm(mile_sampler *s, const GradParams &gp, int E, hipStr
       // dW[in][out] (+)= in^T dz, written straight into the slab at the kernel's offset
       if (gemm(RB_OP_N, RB_OP_T, fout, fin, Rc, dz, fout, (long long)Rc * fout, in, fin, sin, beta, slab + ds.w_off[l], fout, dp))
         return fail(MILE_ERR_HIP, "rocblas sgemm (dW) failed");
-      k_gemm_colsum<<<dim3((fout + 63) / 64, E), 256, 0, st>>>(dz, Rc, fout, slab + ds.b_off[l], dp, chunk != 0);
+      if (gemm(RB_OP_N, RB_OP_N, fout, 1, Rc, dz, fout, (long long)Rc * fout, s->gemm_ones, Rc, 0, beta, slab + ds.b_off[l], fout, dp))
+        return fail(MILE_ERR_HIP, "rocblas sgemm (bias gradient) failed");
       if (l > 0) {
         if (gemm(RB_OP_T, RB_OP_N, fin, Rc, fout, gp.theta + ds.w_off[l], fout, d, dz, fout, (long long)Rc * fout, &zero, tmp[pp], fin,
                  (long long)Rc * fin))
