@@ -302,6 +302,30 @@ def test_train_cli_runs_the_yaml_surface(tmp_path):
     assert 'time.sampling took' in log and 'Starting mclmc Sampling' in log
 
 
+def test_train_cli_classification_wide_net(tmp_path):
+    """The YAML surface on a covertype-shaped problem (7 classes, wide hidden layers -> the layer-wise
+    SGEMM path chosen by AUTO, the host-driven tuner because d > 16384)."""
+    import yaml
+    cfg = yaml.safe_load((ROOT / 'experiments' / 'mclmc_covertype_b4.yaml').read_text())
+    cfg['saving_dir'] = str(tmp_path)
+    cfg['experiment_name'] = 'b4_small'
+    cfg['data']['path'] = '1500x54'
+    cfg['model']['hidden_structure'] = [128, 128, 7]
+    # phase 2 estimates L = sqrt(sum(E[x^2] - E[x]^2)) in fp32 as the reference does (warmup.py:204-228): with
+    # prior-scale positions that difference only rises above rounding after a few dozen steps, hence 400 here
+    cfg['training']['sampler'].update(warmup_steps=400, n_samples=20, n_chains=3, desired_energy_var_start=5e-4,
+                                      desired_energy_var_end=1e-4)
+    (tmp_path / 'cfg.yaml').write_text(yaml.safe_dump(cfg))
+    r = subprocess.run([sys.executable, str(ROOT / 'train.py'), '-c', str(tmp_path / 'cfg.yaml'), '-d', '1'],
+                       capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    exp = tmp_path / 'b4_small'
+    assert sorted(p.name for p in (exp / 'samples').iterdir() if p.is_dir()) == ['0', '1', '2']
+    z = np.load(exp / 'samples' / '1' / 'sample_10.npz')
+    assert z['fcn.layer0.kernel'].shape == (54, 128) and z['fcn.layer2.bias'].shape == (7,)
+    assert all(np.isfinite(z[k]).all() for k in z.files)
+
+
 def test_lppd_matches_oracle_after_equal_step_count(oracle):
     """The +-1 % LPPD gate of BASELINE.json on a short equal-noise run."""
     from mile_amd.metrics import lppd, pointwise_lppd, predict

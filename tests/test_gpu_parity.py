@@ -182,3 +182,37 @@ def test_steps_match_oracle_explicit_noise(oracle, kernel, refresh):
     assert _relerr(samples.cpu().numpy(), np.stack(kept)) < 1e-4
     # the input state was not modified (functional step)
     assert torch.equal(s0.position.cpu(), torch.from_numpy(prob['theta0']))
+
+
+@pytest.mark.parametrize('per_call', [1, 3])
+def test_steps_match_oracle_beyond_the_register_cached_update(oracle, per_call):
+    """d > 16384 floats takes the two-pass update kernel (k_update) instead of k_update_fast; one-step calls
+    are what the host-driven tuner issues for such nets."""
+    ospec = oracle.ModelSpec(9, (128, 128, 2))
+    assert ospec.n_params > 16384
+    N, E, T = 80, 3, 6
+    prob = oracle.synthetic_problem(ospec, N, E, seed=21)
+    rng = np.random.default_rng(6)
+    d = ospec.n_params
+    z0 = rng.standard_normal((E, d)).astype(np.float32)
+    noise = rng.standard_normal((T, 2, E, d)).astype(np.float32)
+    f = lambda th: oracle.logpost_and_grad(ospec, th, prob['X'], prob['y'])
+    st = oracle.mclmc_init(f, prob['theta0'].astype(np.float64), z0.astype(np.float64))
+    infos = []
+    for i in range(T):
+        st, info = oracle.mclmc_step(f, st, prob['eps'].astype(np.float64), prob['L'].astype(np.float64),
+                                     noise[i, 0].astype(np.float64), noise[i, 1].astype(np.float64))
+        infos.append(info.energy_change)
+    eng = _engine(oracle, ospec, prob, 'gemm_f32')
+    s = eng.init(torch.from_numpy(prob['theta0']), noise=torch.from_numpy(z0))
+    got = []
+    for i in range(0, T, per_call):
+        s, info, _ = eng.step(s, torch.from_numpy(prob['eps']), torch.from_numpy(prob['L']), n_steps=per_call,
+                              noise=torch.from_numpy(noise[i:i + per_call]), step_offset=i)
+        got.append(info.energy_change.cpu().numpy())
+    torch.cuda.synchronize()
+    assert _relerr(s.position.cpu().numpy(), st.position) < 1e-4
+    assert np.abs(s.momentum.cpu().numpy() - st.momentum).max() < 1e-4 * np.abs(st.momentum).max() + 1e-6
+    assert _relerr(s.logdensity.cpu().numpy(), st.logdensity) < 1e-5
+    assert _relerr(s.logdensity_grad.cpu().numpy(), st.logdensity_grad) < 1e-3
+    assert np.abs(np.concatenate(got) - np.stack(infos)).max() < 5e-3
