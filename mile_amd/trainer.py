@@ -3,11 +3,12 @@
 In scope: directory / logging setup, data loading, the probabilistic model, ``train_plan``
 chain grouping and ``start_sampling``.  Out of scope this round: the optax
 warm-start training loop -- chains start from ``warmstart_exp_dir`` params if given, else from
-the prior's initialiser (what the reference does when warm-start is disabled, trainer.py:569-573).
+``module.init``'s distribution (what the reference does when warm-start is disabled, trainer.py:569-573).
 """
 from __future__ import annotations
 
 import logging
+import math
 import os
 import time
 from contextlib import contextmanager
@@ -76,13 +77,21 @@ class BDETrainer:
         return k
 
     def init_module_params(self, chain_ids) -> np.ndarray:
-        """Random ParamTree from the prior's initialiser, one stream per GLOBAL chain id."""
+        """Random parameters as `module.init` gives them (trainer.py:206-228, 904-917): flax Dense defaults --
+        kernel lecun_normal (truncated normal on [-2, 2] standard deviations, variance 1/fan_in), bias zeros --
+        one stream per GLOBAL chain id.  (JAX's PRNG is not reproducible here; the distribution is.)"""
         spec = self.prob_model.spec
-        prior = self.config.training.sampler.prior
         rows = []
         for cid in chain_ids:
             g = torch.Generator().manual_seed((self.config.rng * 1000003 + int(cid)) & 0x7FFFFFFFFFFFFFFF)
-            rows.append(prior.f_init(g, (spec.n_params,)).numpy())
+            flat = torch.zeros(spec.n_params, dtype=torch.float32)
+            for name, off, shape in spec.leaves():
+                if name.endswith('kernel'):
+                    w = torch.empty(shape, dtype=torch.float32)
+                    torch.nn.init.trunc_normal_(w, mean=0.0, std=1.0, a=-2.0, b=2.0, generator=g)
+                    # variance_scaling(1.0, 'fan_in', 'truncated_normal'): std = sqrt(1/fan_in) / 0.87962566...
+                    flat[off:off + w.numel()] = (w * (math.sqrt(1.0 / shape[0]) / 0.87962566103423978)).reshape(-1)
+            rows.append(flat.numpy())
         return np.stack(rows).astype(np.float32)
 
     def train_bde(self):
@@ -94,7 +103,7 @@ class BDETrainer:
         ws = self.config.training.warmstart
         if ws.include and not ws.warmstart_exp_dir:
             logger.warning('\t| warm-start training (optax deep ensemble) is outside the MI355X hot path: '
-                           'chains start from the prior initialiser; set warmstart_exp_dir to reuse trained members.')
+                           'chains start from module.init-style random parameters; set warmstart_exp_dir to reuse trained members.')
         wdir = self.exp_dir / ws._dir_name
         if self.rank == 0 and not ws.warmstart_exp_dir:
             params = self.init_module_params(range(self.n_chains))
