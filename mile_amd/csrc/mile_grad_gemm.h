@@ -1,6 +1,7 @@
 // Layer-wise gradient path for wide FCNs (MILE_GRAD_GEMM_F32): the Dense products are plain strided
 // batched SGEMMs (rocBLAS, one batch entry per particle, weights read in place from the [E, d]
-// parameter array, weight gradients accumulated in place into the slab), everything between them is
+// parameter array, weight gradients accumulated in place into the slab, bias gradients as the skinny product dZ^T 1),
+// everything between them is
 // the elementwise HIP kernels below.  fp32 throughout: same numerics class as k_grad_generic, which
 // it replaces where hidden widths are large enough for a library GEMM to win (B3/B4-class nets; the
 // fused kernels k_grad_w64 / k_grad_w128b cover the shapes they were written for).
@@ -65,23 +66,6 @@ __global__ __launch_bounds__(256) void k_gemm_head(float *out, const void *y, lo
   if (tid == 0) {
     const float t = (red[0] + red[1]) + (red[2] + red[3]);
     llacc[e] = first_chunk ? t : llacc[e] + t;
-  }
-}
-
-// Bias gradient: dst[e*dst_stride + o] (+)= sum_r dZ[e][r][o].  grid (ceil(W/64), E), 256 threads.
-__global__ __launch_bounds__(256) void k_gemm_colsum(const float *dZ, int R, int W, float *dst, long long dst_stride, int accumulate) {
-  __shared__ float red[4][64];
-  const int e = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-  const float *z = dZ + (size_t)e * R * W;
-  float s = 0.0f;
-  if (c < W)
-    for (int r = q; r < R; r += 4) s += z[(size_t)r * W + c];
-  red[q][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (q == 0 && c < W) {
-    const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    float *p = dst + (size_t)e * dst_stride + c;
-    *p = accumulate ? *p + t : t;
   }
 }
 

@@ -1,4 +1,4 @@
-// k_grad_w128b<NH>: full-batch log-likelihood gradient of a ReLU regression FCN with NH (1..3)
+// k_grad_w128b<NH, RT>: full-batch log-likelihood gradient of a ReLU regression FCN with NH (1..3)
 // hidden layers of width 128 (config B3: [9 -> 128 -> 128 -> 128 -> 2]), bf16 MFMA operands with
 // fp32 accumulation (v_mfma_f32_32x32x16_bf16).  Parameters stay fp32 in HBM; weights, inputs,
 // activations and back-propagated signals are rounded to bf16 where they enter a matrix product --
@@ -18,10 +18,20 @@
 // forward (transposed read) and backward (row read) the same way.
 //
 // One wave per SIMD leaves nobody to hide a wave's own LDS latency, MFMA drain and barrier waits, so
-// each iteration walks RT = 2 independent row tiles between the same 2*NH+1 barriers: the second
-// tile's loads and MFMAs fill the first tile's epilogue and vice versa, and the barrier cost per
-// tile halves.  Bias gradients are column sums of the same transposed dZ fragments the dW products
-// read (v_dot2c_f32_bf16 against ones), which keeps 64 accumulator registers free for that.
+//  * each iteration walks RT = 2 row tiles between the same 2*NH barriers; they share every weight
+//    fragment, and the barrier cost per tile halves;
+//  * all fragment reads of a phase are issued before its first MFMA (sched_barrier fences: left alone,
+//    the compiler sinks every read next to its use and pays the LDS latency once per MFMA); in the
+//    backward layers the transposed dW operands are read between the dH MFMAs and the dZ epilogue
+//    runs between the dW MFMAs;
+//  * epilogues are packed: the bias tile is the first MFMA's C operand, ReLU and its derivative are
+//    16-bit integer ops on bf16 bit patterns, bias gradients are v_dot2c_f32_bf16 column sums of the
+//    transposed dZ fragments the dW products read anyway;
+//  * the head never touches a full H: each wave multiplies its own H tile straight from the
+//    accumulator registers into partial (mu, log sigma), the partials meet in LDS behind the barrier
+//    the forward pass needs anyway, and d(out) reaches dH from registers and the head-weight product
+//    through a private 128-byte transposed buffer.
+// Measured history and counters: profiles/r01/07_b3_bf16_notes.md.
 #pragma once
 #include "mile_bf16_frag.h"
 #include "mile_device.h"
@@ -80,29 +90,6 @@ __device__ __forceinline__ void store_group_masked(char *dst, const f32x4_t v, c
     o[k] = t;
   }
   *reinterpret_cast<f32x2_t *>(dst) = o;
-}
-
-// dZ = dH * relu'(z) as bf16 into dzimg; relu'(z) = (H != 0) is read back from this wave's own slice of the
-// H image (bit patterns: min(H, 1) is 0 or 1, times the dZ bits: v_pk_min_u16 + v_pk_mul_lo_u16).
-__device__ __forceinline__ void store_tile_masked(char *dzimg, const char *himg, int col0, const f32x16 &dh, int lane) {
-  const int r = lane & 31, h = lane >> 5;
-  const uint32_t ones = 0x00010001u;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int off = img_off(r, (col0 >> 3) + g) + 8 * h;
-    const f32x4_t v = {dh[4 * g], dh[4 * g + 1], dh[4 * g + 2], dh[4 * g + 3]};
-    const f32x2_t b = __builtin_bit_cast(f32x2_t, __builtin_convertvector(v, bf16x4));   // two packed pairs
-    const f32x2_t hb = *reinterpret_cast<const f32x2_t *>(himg + off);
-    f32x2_t o;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {   // inline asm: the compiler would turn x * min(h, 1) back into compare + select
-      float m, t;
-      asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(hb[k]), "v"(ones));
-      asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(t) : "v"(b[k]), "v"(m));
-      o[k] = t;
-    }
-    *reinterpret_cast<f32x2_t *>(dzimg + off) = o;
-  }
 }
 
 template <int NH, int RT>

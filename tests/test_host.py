@@ -135,6 +135,45 @@ def test_config_accepts_reference_schema_and_rejects_unknown_keys(tmp_path):
     assert s.kernel is KERNELS['mclmc'] and WARMUP_KERNELS == {}
 
 
+def test_config_grad_kernel_extension_and_all_experiment_yamls_parse():
+    from mile_amd.config import Config, ConfigError
+    names = {}
+    for f in sorted((ROOT / 'experiments').glob('*.yaml')):
+        c = Config.from_file(f)
+        names[f.name] = c.training.sampler.grad_kernel
+    assert names['mclmc_protein_b3.yaml'] == 'mfma_w128_bf16' and names['mclmc_airfoil_b2.yaml'] == 'auto'
+    b4 = Config.from_file(ROOT / 'experiments' / 'mclmc_covertype_b4.yaml')
+    assert b4.model.hidden_structure == [256, 256, 256, 256, 7] and b4.n_chains == 1024 and b4.data.task == 'class'
+    d = b4.to_dict()
+    d['training']['sampler']['grad_kernel'] = 'fp8_magic'
+    with pytest.raises(ConfigError, match='grad_kernel'):
+        Config.from_dict(d)
+
+
+def test_random_chain_init_follows_flax_dense_defaults(tmp_path):
+    """Without warm-start parameters the reference starts chains from module.init (trainer.py:206-228,904-917):
+    nn.Dense defaults = lecun_normal kernels (truncated at 2 sigma, variance 1/fan_in), zero biases."""
+    import yaml
+    from mile_amd.config import Config
+    from mile_amd.trainer import BDETrainer
+    cfg = yaml.safe_load((ROOT / 'experiments' / 'smoke_synthetic.yaml').read_text())
+    cfg['saving_dir'] = str(tmp_path)
+    (tmp_path / 'c.yaml').write_text(yaml.safe_dump(cfg))
+    tr = BDETrainer(Config.from_file(tmp_path / 'c.yaml'))
+    w = tr.init_module_params([0, 1, 7])
+    assert w.shape == (3, tr.prob_model.spec.n_params) and w.dtype == np.float32
+    assert not np.array_equal(w[0], w[1])
+    assert np.array_equal(w[2], tr.init_module_params([7])[0])          # stream keyed by the global chain id
+    for name, off, shape in tr.prob_model.spec.leaves():
+        v = w[:, off:off + int(np.prod(shape))]
+        if name.endswith('bias'):
+            assert not v.any()
+        else:
+            sd = math.sqrt(1.0 / shape[0])
+            assert abs(v.std() / sd - 1.0) < 0.1, (name, v.std(), sd)
+            assert np.abs(v).max() <= 2.0 * sd / 0.87962566103423978 + 1e-6
+
+
 def test_train_plan_matches_reference_semantics():
     from mile_amd.sampling import kept_indices
     from mile_amd.trainer import train_plan
