@@ -33,6 +33,18 @@ E_PER_GPU = 128
 N_THINNING = 10
 CHUNK = 50                       # steps per sample-collection chunk
 PEAK_FP32_MFMA_TFLOPS = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 (same guide; never the 2:1-sparsity figure)
+
+# The driver's bench line is B2 (the default).  --workload B3 reports BASELINE configs[2] in the same format.
+WORKLOADS = {
+    'B2': dict(ensemble=128, kernel='auto', dtype='f32', peak=PEAK_FP32_MFMA_TFLOPS, steps=400, warmup=50, cpu_particles=None,
+               text='B2: airfoil-shaped N=1052 F=5, FCN hidden_structure [64,64,64,2] relu, Gaussian head, '
+                    'StandardNormal prior, d=8834'),
+    'B3': dict(ensemble=512, kernel='mfma_w128_bf16', dtype='bf16', peak=PEAK_BF16_MFMA_TFLOPS, steps=40, warmup=5,
+               cpu_particles=16,
+               text='B3: protein-shaped N=36000 F=9, FCN hidden_structure [128,128,128,2] relu, Gaussian head, '
+                    'StandardNormal prior, d=34562; bf16 matrix operands, fp32 accumulation/parameters/integrator'),
+}
 
 
 def grad_flops_per_particle(F, hs, N):
@@ -70,7 +82,7 @@ def cpu_baseline(spec_o, prob, oracle, seconds_target=15.0):
             if el > seconds_target or n >= 400:
                 break
         return {'value': E * n / el, 'unit': 'particle-steps/s', 'cores': int(port.threads), 'kind': 'port',
-                'sample': f'{n} MCLMC steps of all {E} particles (oracle/cpu_mclmc.c, fp32, OpenMP threads='
+                'sample': f'{n} MCLMC steps of {E} particles of the workload (oracle/cpu_mclmc.c, fp32, OpenMP threads='
                           f'{port.threads}, one particle per thread), {el:.1f} s'}
     except Exception as exc:                                                # noqa: BLE001
         note = f' [C port unavailable: {type(exc).__name__}]'
@@ -99,14 +111,20 @@ def cpu_baseline(spec_o, prob, oracle, seconds_target=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=400)
-    ap.add_argument('--warmup', type=int, default=50)
-    ap.add_argument('--ensemble', type=int, default=E_PER_GPU, help='particles per GPU')
-    ap.add_argument('--grad-kernel', default='auto')
+    ap.add_argument('--workload', default=WORKLOAD, choices=sorted(WORKLOADS))
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=None)
+    ap.add_argument('--ensemble', type=int, default=None, help='particles per GPU')
+    ap.add_argument('--grad-kernel', default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--force-dist', action='store_true', help='init the process group even for 1 rank (rehearsal)')
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    args.steps = wl['steps'] if args.steps is None else args.steps
+    args.warmup = wl['warmup'] if args.warmup is None else args.warmup
+    args.ensemble = wl['ensemble'] if args.ensemble is None else args.ensemble
+    args.grad_kernel = wl['kernel'] if args.grad_kernel is None else args.grad_kernel
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -131,7 +149,7 @@ def main():
     from mile_amd import ModelSpec
     from mile_amd.engine import Engine
 
-    spec_o, N, _ = oracle.config_spec(WORKLOAD)
+    spec_o, N, _ = oracle.config_spec(args.workload)
     E = args.ensemble
     prob = oracle.synthetic_problem(spec_o, N, E * world, seed=0)
     lo, hi = rank * E, (rank + 1) * E
@@ -193,10 +211,11 @@ def main():
         info = eng.grad_launch_info(E)
         traffic = None   # PMC counters cannot be read from inside the run: last committed measurement
         tj = ROOT / 'profiles' / 'r01' / 'traffic.json'
-        if tj.exists() and E == E_PER_GPU and info['kernel'] == 'k_grad_w64':
+        if tj.exists() and args.workload == 'B2' and E == E_PER_GPU and info['kernel'] == 'k_grad_w64':
             traffic = json.loads(tj.read_text())['hbm_bytes_per_launch']
-        roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
+        peak = wl['peak'] if eng.grad_kernel == 'mfma_w128_bf16' or args.workload == 'B2' else PEAK_FP32_MFMA_TFLOPS
+        roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak,
+                'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic,
                 'kernel': info['kernel'], 'grid': list(info['grid']), 'lds_bytes': info['lds_bytes'],
                 'avg_launch_us': round(avg_s * 1e6, 2), 'launches_timed': n_launch,
                 'flop_per_launch': flops}
@@ -206,7 +225,8 @@ def main():
     if rank == 0:
         cpu = None
         if not args.no_cpu_baseline:
-            prob1 = {k: (v[:E] if k in ('theta0', 'u0', 'eps', 'L') else v) for k, v in prob.items()}
+            Ec = E if wl['cpu_particles'] is None else min(E, wl['cpu_particles'])   # bounded sample
+            prob1 = {k: (v[:Ec] if k in ('theta0', 'u0', 'eps', 'L') else v) for k, v in prob.items()}
             cpu = cpu_baseline(spec_o, prob1, oracle)
         value = E * world * args.steps / el
         out = {
@@ -220,10 +240,9 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32',
+            'dtype': wl['dtype'] if eng.grad_kernel == 'mfma_w128_bf16' or args.workload == 'B2' else 'f32',
             'data': 'synthetic',
-            'config': {'workload': 'B2: airfoil-shaped N=1052 F=5, FCN hidden_structure [64,64,64,2] relu, '
-                                   'Gaussian head, StandardNormal prior, d=8834',
+            'config': {'workload': wl['text'],
                        'ensemble_per_gpu': E, 'ensemble_total': E * world, 'n_thinning': N_THINNING,
                        'integrator': 'isokinetic McLachlan, O-step-O refresh, 2 full-batch gradients/step',
                        'noise': 'Philox4x32-10 counter RNG', 'grad_kernel': eng.grad_kernel,
