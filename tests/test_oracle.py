@@ -271,3 +271,41 @@ def test_bf16_round_matches_torch_and_recipe_is_close(oracle):
     lpb, gb = oracle.logpost_and_grad_bf16(sp, th, pr['X'], pr['y'])
     assert np.abs(lpb - lp).max() < 5e-3 * np.abs(lp).max()
     assert (np.linalg.norm(gb - g, axis=1) / np.linalg.norm(g, axis=1)).max() < 5e-2
+
+
+@pytest.mark.parametrize('C,H,W,K,act,task', [(1, 28, 28, 10, 'relu', 'classification'), (3, 32, 32, 10, 'tanh', 'classification'),
+                                               (2, 13, 17, 2, 'sigmoid', 'regr')])
+def test_lenet_oracle_matches_torch_autograd(C, H, W, K, act, task):
+    """The LeNet restatement (oracle/lenet_oracle.py, src/models/images/cnns.py:33-66) against an independent
+    fp64 implementation: torch conv2d / avg_pool2d / autograd."""
+    torch = pytest.importorskip('torch')
+    from oracle import lenet_oracle as LN
+    spec = LN.LeNetSpec(C, H, W, K, activation=act, task=task, prior='Laplace' if act == 'tanh' else 'Normal', prior_scale=0.8)
+    prob = LN.synthetic_problem(spec, 7, 2, seed=1)
+    th = prob['theta0'].astype(np.float64)
+    lp, g = LN.logpost_and_grad(spec, th, prob['X'], prob['y'])
+    F = torch.nn.functional
+    a = {'relu': torch.relu, 'tanh': torch.tanh, 'sigmoid': torch.sigmoid}[act]
+    X = torch.tensor(prob['X'], dtype=torch.float64)
+    for e in range(2):
+        t = torch.tensor(th[e], requires_grad=True)
+        P = {n: t[o:o + int(np.prod(sh))].reshape(sh) for n, o, sh in spec.leaves()}
+        x = F.conv2d(X, P['core.conv1.kernel'].permute(3, 2, 0, 1), P['core.conv1.bias'], padding=2)
+        x = F.avg_pool2d(a(x), 2)
+        x = F.conv2d(x, P['core.conv2.kernel'].permute(3, 2, 0, 1), P['core.conv2.bias'])
+        x = F.avg_pool2d(a(x), 2).permute(0, 2, 3, 1).reshape(7, -1)
+        x = a(x @ P['core.fc1.kernel'] + P['core.fc1.bias'])
+        x = a(x @ P['core.fc2.kernel'] + P['core.fc2.bias'])
+        out = x @ P['core.fc3.kernel'] + P['core.fc3.bias']
+        if task == 'regr':
+            sig = torch.exp(out[:, 1]).clamp(1e-6, 1e6)
+            ll = torch.distributions.Normal(out[:, 0], sig).log_prob(torch.tensor(prob['y'], dtype=torch.float64)).sum()
+        else:
+            ll = -F.cross_entropy(out, torch.tensor(prob['y'], dtype=torch.long), reduction='sum')
+        loc, sc = torch.zeros((), dtype=torch.float64), torch.tensor(0.8, dtype=torch.float64)
+        pr = (torch.distributions.Normal(loc, sc) if spec.prior == 'Normal' else torch.distributions.Laplace(loc, sc)).log_prob(t).sum()
+        tot = ll + pr
+        tot.backward()
+        assert abs(tot.item() - lp[e]) < 1e-9 * abs(lp[e])
+        assert np.abs(t.grad.numpy() - g[e]).max() < 1e-9 * np.abs(g[e]).max()
+    assert spec.n_params == {(1, 28, 28, 10): 61706, (3, 32, 32, 10): 83126}.get((C, H, W, K), spec.n_params)
