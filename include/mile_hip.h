@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MILE_ABI_VERSION 1
+#define MILE_ABI_VERSION 2
 #define MILE_MAX_LAYERS 16
 
 typedef enum mile_status {
@@ -64,8 +64,11 @@ typedef enum mile_grad_kernel {
   MILE_GRAD_GENERIC = 1,          /* any FCN, fp32 VALU */
   MILE_GRAD_MFMA_W64 = 2,         /* ReLU regression, 1-3 hidden layers of width 64, fp32 MFMA */
   MILE_GRAD_MFMA_W128_BF16 = 3,   /* ReLU regression, 1-3 hidden layers of width 128, bf16 MFMA */
-  MILE_GRAD_GEMM_F32 = 4          /* any FCN, fp32: rocBLAS strided-batched SGEMMs + elementwise HIP kernels (wide nets) */
+  MILE_GRAD_GEMM_F32 = 4,         /* any FCN, fp32: rocBLAS strided-batched SGEMMs + elementwise HIP kernels (wide nets) */
+  MILE_GRAD_LENET_F32 = 5         /* MILE_MODEL_LENET only: im2col + the same SGEMMs, pooling / col2im HIP kernels */
 } mile_grad_kernel;
+/* Which network: the FCN (src/models/tabular/fcn.py:16-28) or LeNet (src/models/images/cnns.py:10-66). */
+typedef enum mile_model { MILE_MODEL_FCN = 0, MILE_MODEL_LENET = 1 } mile_model;
 
 /* FCNConfig (src/config/models/fcn.py:7-30) + PriorConfig (src/config/sampler.py:60-95)
  * + Task: everything log_unnormalized_posterior (src/training/probabilistic.py:115-138)
@@ -80,6 +83,10 @@ typedef struct mile_model_spec {
   float prior_loc;
   float prior_scale;
   int32_t use_bias;                  /* FCNConfig.use_bias; only 1 is supported */
+  int32_t model;                     /* mile_model.  LENET: X rows are NCHW images, in_features = C*H*W,
+                                      * n_layers = 1 and widths[0] = out_dim; parameter order is ravel_pytree's
+                                      * (conv1, conv2, fc1, fc2, fc3; bias before kernel [kh,kw,in,out]) */
+  int32_t img_c, img_h, img_w;       /* LENET image geometry (ignored for the FCN) */
 } mile_model_spec;
 
 /* blackjax IntegratorState(position, momentum, logdensity, logdensity_grad) for an

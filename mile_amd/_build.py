@@ -14,7 +14,7 @@ CSRC = PKG_DIR / 'csrc'
 LIB_PATH = PKG_DIR / 'libmile_hip.so'
 SOURCES = ['mile_hip.hip']
 HEADERS = ['mile_device.h', 'mile_grad_generic.h', 'mile_grad_w64.h', 'mile_grad_w64_block.inc', 'mile_bf16_frag.h',
-           'mile_grad_w128b.h', 'mile_grad_gemm.h', 'mile_predict.h', 'mile_update.h']
+           'mile_grad_w128b.h', 'mile_grad_gemm.h', 'mile_lenet.h', 'mile_predict.h', 'mile_update.h']
 
 
 def _hipcc() -> str:

@@ -7,13 +7,13 @@ from pathlib import Path
 from mile_amd._build import LIB_PATH
 
 MILE_MAX_LAYERS = 16
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ACTIVATION_IDS = {'relu': 0, 'tanh': 1, 'sigmoid': 2}
 TASK_IDS = {'regr': 0, 'regression': 0, 'classification': 1, 'class': 1}
 PRIOR_IDS = {'Normal': 0, 'StandardNormal': 0, 'Laplace': 1}
 REFRESH_IDS = {'O-step-O': 0, 'step-O': 1}
-GRAD_KERNEL_IDS = {'auto': 0, 'generic': 1, 'mfma_w64': 2, 'mfma_w128_bf16': 3, 'gemm_f32': 4}
+GRAD_KERNEL_IDS = {'auto': 0, 'generic': 1, 'mfma_w64': 2, 'mfma_w128_bf16': 3, 'gemm_f32': 4, 'lenet_f32': 5}
 
 
 class ModelSpecC(C.Structure):
@@ -27,6 +27,10 @@ class ModelSpecC(C.Structure):
         ('prior_loc', C.c_float),
         ('prior_scale', C.c_float),
         ('use_bias', C.c_int32),
+        ('model', C.c_int32),
+        ('img_c', C.c_int32),
+        ('img_h', C.c_int32),
+        ('img_w', C.c_int32),
     ]
 
 

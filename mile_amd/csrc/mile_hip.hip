@@ -17,6 +17,7 @@
 #include "mile_grad_w64.h"
 #include "mile_grad_w128b.h"
 #include "mile_grad_gemm.h"
+#include "mile_lenet.h"
 #include "mile_predict.h"
 #include "mile_update.h"
 
@@ -47,6 +48,7 @@ struct mile_sampler {
   float *ev_X = nullptr, *ev_Xp = nullptr; void *ev_y = nullptr; int ev_cap = 0;   // evaluation (test) set staging
   float *alt_x = nullptr, *alt_u = nullptr, *alt_g = nullptr, *alt_logp = nullptr;   // ping-pong state of mile_tune
   int grad_kernel = MILE_GRAD_AUTO;
+  LeNetGeom lg{};                       // MILE_MODEL_LENET geometry and parameter offsets
   // layer-wise GEMM path (MILE_GRAD_GEMM_F32): rocBLAS handle and activation workspace
   void *blas = nullptr;
   float *gemm_ws = nullptr, *gemm_ones = nullptr;
@@ -60,6 +62,7 @@ struct mile_sampler {
 };
 
 static bool w64_supported(const mile_model_spec &sp) {
+  if (sp.model != MILE_MODEL_FCN) return false;
   if (sp.task != MILE_TASK_REGRESSION || sp.activation != MILE_ACT_RELU) return false;
   const int nh = sp.n_layers - 1;
   if (nh < 1 || nh > 3) return false;
@@ -104,12 +107,14 @@ static bool rocblas_load() {
 
 // library GEMMs pay off once the hidden layers are wide; below that the single-launch generic kernel wins
 static bool gemm_preferred(const mile_model_spec &sp) {
+  if (sp.model != MILE_MODEL_FCN) return false;
   int mw = 0;
   for (int l = 0; l + 1 < sp.n_layers; ++l) mw = std::max(mw, sp.widths[l]);
   return sp.n_layers >= 2 && mw >= 96;
 }
 
 static bool w128b_supported(const mile_model_spec &sp) {
+  if (sp.model != MILE_MODEL_FCN) return false;
   if (sp.task != MILE_TASK_REGRESSION || sp.activation != MILE_ACT_RELU) return false;
   const int nh = sp.n_layers - 1;
   if (nh < 1 || nh > 3) return false;
@@ -121,6 +126,7 @@ static bool w128b_supported(const mile_model_spec &sp) {
 }
 
 static int resolved_kernel(const mile_sampler *s) {
+  if (s->spec.model == MILE_MODEL_LENET) return MILE_GRAD_LENET_F32;
   if (s->grad_kernel == MILE_GRAD_AUTO) {
     if (w64_supported(s->spec)) return MILE_GRAD_MFMA_W64;
     return gemm_preferred(s->spec) && rocblas_load() ? MILE_GRAD_GEMM_F32 : MILE_GRAD_GENERIC;
@@ -143,7 +149,7 @@ static int choose_S(const mile_sampler *s, int E, int kernel) {
     S = std::min(S, std::max(1, NB / 4));  // keep >= 4 row blocks (one per wave) per workgroup
     return S;
   }
-  if (kernel == MILE_GRAD_GEMM_F32) return 1;
+  if (kernel == MILE_GRAD_GEMM_F32 || kernel == MILE_GRAD_LENET_F32) return 1;
   if (kernel == MILE_GRAD_MFMA_W128_BF16) {
     const int NBS = s->Npb / 64;              // iterations of two 32-row tiles
     int S = std::max(1, s->n_cu / std::max(E, 1));
@@ -172,6 +178,15 @@ int32_t mile_create(const mile_model_spec *spec, int32_t device, mile_sampler **
     if (spec->widths[l] < 1) return fail(MILE_ERR_INVALID, "layer width must be >= 1");
   if (spec->task == MILE_TASK_REGRESSION && spec->widths[spec->n_layers - 1] != 2)
     return fail(MILE_ERR_INVALID, "regression needs an output layer of width 2 (mu, log sigma)");
+  if (spec->model != MILE_MODEL_FCN && spec->model != MILE_MODEL_LENET) return fail(MILE_ERR_INVALID, "unknown model");
+  if (spec->model == MILE_MODEL_LENET) {
+    if (spec->n_layers != 1) return fail(MILE_ERR_INVALID, "LeNet: n_layers must be 1 (widths[0] = out_dim)");
+    if (spec->img_c < 1 || spec->img_h < 1 || spec->img_w < 1 ||
+        (long long)spec->img_c * spec->img_h * spec->img_w != spec->in_features)
+      return fail(MILE_ERR_INVALID, "LeNet: in_features must equal img_c * img_h * img_w");
+    if ((spec->img_h / 2 - 4) / 2 < 1 || (spec->img_w / 2 - 4) / 2 < 1) return fail(MILE_ERR_INVALID, "LeNet: image too small");
+    if (!rocblas_load()) return fail(MILE_ERR_HIP, "LeNet needs librocblas.so, which could not be loaded");
+  }
 
   auto *s = new mile_sampler();
   s->spec = *spec;
@@ -184,6 +199,31 @@ int32_t mile_create(const mile_model_spec *spec, int32_t device, mile_sampler **
   ds.prior = spec->prior;
   ds.prior_loc = spec->prior_loc;
   ds.prior_scale = spec->prior_scale;
+  if (spec->model == MILE_MODEL_LENET) {   // ravel_pytree order of {'core': {conv1, conv2, fc1, fc2, fc3}}: bias, kernel each
+    LeNetGeom &g = s->lg;
+    g.C = spec->img_c; g.H = spec->img_h; g.W = spec->img_w; g.K = spec->widths[0];
+    g.hp1 = g.H / 2; g.wp1 = g.W / 2; g.h2 = g.hp1 - 4; g.w2 = g.wp1 - 4; g.hp2 = g.h2 / 2; g.wp2 = g.w2 / 2;
+    g.flat = g.hp2 * g.wp2 * 16;
+    long long o = 0;
+    g.b_c1 = (int)o; o += 6;   g.k_c1 = (int)o; o += 25LL * g.C * 6;
+    g.b_c2 = (int)o; o += 16;  g.k_c2 = (int)o; o += 150LL * 16;
+    g.b_f1 = (int)o; o += 120; g.k_f1 = (int)o; o += (long long)g.flat * 120;
+    g.b_f2 = (int)o; o += 84;  g.k_f2 = (int)o; o += 120LL * 84;
+    g.b_f3 = (int)o; o += g.K; g.k_f3 = (int)o; o += 84LL * g.K;
+    if (o > 0x7fffffffLL) { delete s; return fail(MILE_ERR_INVALID, "parameter count exceeds int32"); }
+    g.d = (int)o;
+    ds.d = g.d;
+    ds.widths[0] = g.K;
+    ds.b_off[0] = g.b_c1; ds.w_off[0] = g.k_c1;
+    ds.max_width = 150; ds.act_stride = 0;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) == hipSuccess && device < cnt) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
+    }
+    *out = s;
+    return MILE_OK;
+  }
   // ravel_pytree order: layers sorted by NAME ("layer10" < "layer2"), bias before kernel
   std::vector<int> order(spec->n_layers);
   for (int i = 0; i < spec->n_layers; ++i) order[i] = i;
@@ -261,6 +301,14 @@ int32_t mile_destroy(mile_sampler *s) {
 int64_t mile_param_count(const mile_sampler *s) { return s ? s->ds.d : -1; }
 
 int32_t mile_param_offsets(const mile_sampler *s, int32_t layer, int64_t *bias_off, int64_t *kernel_off) {
+  if (s && s->spec.model == MILE_MODEL_LENET) {   // layers 0..4 = conv1, conv2, fc1, fc2, fc3
+    const LeNetGeom &g = s->lg;
+    const int bo[5] = {g.b_c1, g.b_c2, g.b_f1, g.b_f2, g.b_f3}, ko[5] = {g.k_c1, g.k_c2, g.k_f1, g.k_f2, g.k_f3};
+    if (layer < 0 || layer >= 5) return fail(MILE_ERR_INVALID, "mile_param_offsets: bad layer");
+    if (bias_off) *bias_off = bo[layer];
+    if (kernel_off) *kernel_off = ko[layer];
+    return MILE_OK;
+  }
   if (!s || layer < 0 || layer >= s->ds.n_layers) return fail(MILE_ERR_INVALID, "mile_param_offsets: bad layer");
   if (bias_off) *bias_off = s->ds.b_off[layer];
   if (kernel_off) *kernel_off = s->ds.w_off[layer];
@@ -338,7 +386,9 @@ int32_t mile_reserve(mile_sampler *s, int32_t E) {
 
 int32_t mile_set_grad_kernel(mile_sampler *s, int32_t which) {
   if (!s) return fail(MILE_ERR_INVALID, "null handle");
-  if (which < MILE_GRAD_AUTO || which > MILE_GRAD_GEMM_F32) return fail(MILE_ERR_INVALID, "unknown grad kernel");
+  if (which < MILE_GRAD_AUTO || which > MILE_GRAD_LENET_F32) return fail(MILE_ERR_INVALID, "unknown grad kernel");
+  if ((s->spec.model == MILE_MODEL_LENET) != (which == MILE_GRAD_LENET_F32) && which != MILE_GRAD_AUTO)
+    return fail(MILE_ERR_INVALID, "LENET_F32 is the (only) kernel of MILE_MODEL_LENET");
   if (which == MILE_GRAD_GEMM_F32 && !rocblas_load()) return fail(MILE_ERR_HIP, "GEMM_F32 needs librocblas.so, which could not be loaded");
   if (which == MILE_GRAD_MFMA_W128_BF16 && !w128b_supported(s->spec))
     return fail(MILE_ERR_INVALID, "MFMA_W128_BF16 needs ReLU regression with 1-3 hidden layers of width 128 and F <= 16");
@@ -425,6 +475,119 @@ static int w64_lds_bytes() { return W64Layout<NH, FQ>::BYTES; }
 __global__ void k_fill(float *p, float v, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
+}
+
+// LeNet: forward (+ backward when slab != nullptr) over image chunks; batch = particles (or samples).
+// out_ll != nullptr: evaluation, per-row log-likelihoods out_ll[(s0 + e) * N + r]; otherwise the gradient goes
+// to slab[e * dp + offset] and the log-likelihood sums to llacc[e].
+static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X, const void *y, int N, float *slab, long long dp,
+                     float *llacc, float *out_ll, long long s0, hipStream_t st) {
+  if (!rocblas_load()) return fail(MILE_ERR_HIP, "librocblas.so could not be loaded");
+  const LeNetGeom &g = s->lg;
+  const int d = g.d, act = s->ds.activation, task = s->ds.task;
+  const bool grad = slab != nullptr;
+  if (!s->blas && g_rb.create(&s->blas) != 0) { s->blas = nullptr; return fail(MILE_ERR_HIP, "rocblas_create_handle failed"); }
+  if (g_rb.set_stream(s->blas, st) != 0) return fail(MILE_ERR_HIP, "rocblas_set_stream failed");
+  const size_t HW = (size_t)g.H * g.W, P1 = (size_t)g.hp1 * g.wp1, HW2 = (size_t)g.h2 * g.w2;
+  const size_t n_a1 = 6 * HW, n_p1 = 6 * P1, n_col2 = 150 * HW2, n_a2 = 16 * HW2, n_p2 = g.flat;
+  size_t per = n_a1 + n_p1 + n_col2 + n_a2 + n_p2 + 120 + 84 + g.K;
+  if (grad) per += 84 + 120 + n_p2 + n_a2 + n_p1 + n_a1;
+  const size_t shared = 25 * (size_t)g.C * HW;
+  size_t R = ((size_t)1 << 30) / ((size_t)E * per + shared);
+  R = std::max<size_t>(1, std::min<size_t>(R, (size_t)N));
+  if (const char *rv = getenv("MILE_GEMM_ROWS")) R = std::max<size_t>(1, std::min<size_t>((size_t)atoll(rv), (size_t)N));
+  const size_t need = R * ((size_t)E * per + shared);
+  if (need > s->gemm_ws_floats) {
+    if (s->gemm_ws) (void)hipFree(s->gemm_ws);
+    s->gemm_ws = nullptr; s->gemm_ws_floats = 0;
+    HIP_TRY(hipMalloc(&s->gemm_ws, need * 4));
+    s->gemm_ws_floats = need;
+  }
+  s->gemm_E = 0;
+  const size_t n_ones = R * HW;
+  if ((size_t)s->gemm_ones_n < n_ones) {
+    if (s->gemm_ones) (void)hipFree(s->gemm_ones);
+    s->gemm_ones = nullptr; s->gemm_ones_n = 0;
+    HIP_TRY(hipMalloc(&s->gemm_ones, n_ones * 4));
+    k_fill<<<(unsigned)((n_ones + 255) / 256), 256, 0, st>>>(s->gemm_ones, 1.0f, (int)n_ones);
+    s->gemm_ones_n = (int)n_ones;
+  }
+  const size_t ER = (size_t)E * R;
+  float *q = s->gemm_ws;
+  auto take = [&](size_t n) { float *r = q; q += n; return r; };
+  float *col1 = take(R * shared), *a1 = take(ER * n_a1), *p1 = take(ER * n_p1), *col2 = take(ER * n_col2), *a2 = take(ER * n_a2);
+  float *p2 = take(ER * n_p2), *f1 = take(ER * 120), *f2 = take(ER * 84), *out = take(ER * g.K);
+  float *df2 = nullptr, *df1 = nullptr, *dp2 = nullptr, *dz2 = nullptr, *dp1 = nullptr, *dz1 = nullptr;
+  if (grad) { df2 = take(ER * 84); df1 = take(ER * 120); dp2 = take(ER * n_p2); dz2 = take(ER * n_a2); dp1 = take(ER * n_p1); dz1 = take(ER * n_a1); }
+  const float one = 1.0f, zero = 0.0f;
+  auto blocks = [](long long n) { return (unsigned)std::min<long long>((n + 255) / 256, 65535); };
+  // row-major C[rows x fout] = A[rows x fin] W[fin x fout] per batch entry; W from theta (+ offset), batch stride d
+  auto fwd = [&](int w_off, int fin, int fout, const float *in, long long sin, long long rows, float *o) {
+    return g_rb.sgemm_sb(s->blas, RB_OP_N, RB_OP_N, fout, (int)rows, fin, &one, theta + w_off, fout, d, in, fin, sin, &zero, o, fout,
+                         rows * fout, E);
+  };
+  auto bias_act = [&](float *z, int b_off, int W, long long rows, int apply) {
+    k_gemm_bias_act<<<dim3(blocks(rows * W), E), 256, 0, st>>>(z, theta, b_off, d, W, rows * W, act, apply);
+  };
+  for (int r0 = 0, chunk = 0; r0 < N; r0 += (int)R, ++chunk) {
+    const long long Rc = std::min<long long>((long long)R, N - r0), B = (long long)E * Rc;
+    const long long M1 = Rc * (long long)HW, M2 = Rc * (long long)HW2;
+    // ---- forward
+    k_im2col5<<<blocks(M1 * 25 * g.C), 256, 0, st>>>(X + (size_t)r0 * g.C * HW, col1, Rc, g.H, g.W, g.C, g.H, g.W, 2,
+                                                     (long long)g.C * HW, g.W, 1, (long long)HW);
+    if (fwd(g.k_c1, 25 * g.C, 6, col1, 0, M1, a1)) return fail(MILE_ERR_HIP, "rocblas sgemm (conv1) failed");
+    bias_act(a1, g.b_c1, 6, M1, 1);
+    k_avgpool2<<<blocks(B * (long long)n_p1), 256, 0, st>>>(a1, p1, B, g.H, g.W, 6);
+    k_im2col5<<<blocks(B * (long long)n_col2), 256, 0, st>>>(p1, col2, B, g.hp1, g.wp1, 6, g.h2, g.w2, 0, (long long)n_p1, g.wp1 * 6, 6, 1);
+    if (fwd(g.k_c2, 150, 16, col2, M2 * 150, M2, a2)) return fail(MILE_ERR_HIP, "rocblas sgemm (conv2) failed");
+    bias_act(a2, g.b_c2, 16, M2, 1);
+    k_avgpool2<<<blocks(B * (long long)n_p2), 256, 0, st>>>(a2, p2, B, g.h2, g.w2, 16);
+    if (fwd(g.k_f1, g.flat, 120, p2, Rc * g.flat, Rc, f1)) return fail(MILE_ERR_HIP, "rocblas sgemm (fc1) failed");
+    bias_act(f1, g.b_f1, 120, Rc, 1);
+    if (fwd(g.k_f2, 120, 84, f1, Rc * 120, Rc, f2)) return fail(MILE_ERR_HIP, "rocblas sgemm (fc2) failed");
+    bias_act(f2, g.b_f2, 84, Rc, 1);
+    if (fwd(g.k_f3, 84, g.K, f2, Rc * 84, Rc, out)) return fail(MILE_ERR_HIP, "rocblas sgemm (fc3) failed");
+    bias_act(out, g.b_f3, g.K, Rc, 0);
+    if (!grad) {
+      k_gemm_rowll<<<dim3((unsigned)((Rc + 255) / 256), E), 256, 0, st>>>(out, y, r0, (int)Rc, g.K, task, out_ll, N, s0);
+      continue;
+    }
+    k_gemm_head<<<E, 256, 0, st>>>(out, y, r0, (int)Rc, g.K, task, llacc, chunk == 0);
+    // ---- backward
+    const float *beta = chunk == 0 ? &zero : &one;
+    // dW[fin x fout] (+)= in^T dz into the slab; bias gradient = dz^T 1
+    auto dW = [&](int w_off, int b_off, int fin, int fout, const float *in, long long sin, const float *dz, long long rows) -> int {
+      if (g_rb.sgemm_sb(s->blas, RB_OP_N, RB_OP_T, fout, fin, (int)rows, &one, dz, fout, rows * fout, in, fin, sin, beta, slab + w_off, fout,
+                        dp, E))
+        return 1;
+      return g_rb.sgemm_sb(s->blas, RB_OP_N, RB_OP_N, fout, 1, (int)rows, &one, dz, fout, rows * fout, s->gemm_ones, (int)rows, 0, beta,
+                           slab + b_off, fout, dp, E);
+    };
+    // dX[rows x fin] = dz[rows x fout] W^T
+    auto dX = [&](int w_off, int fin, int fout, const float *dz, long long rows, float *o) {
+      return g_rb.sgemm_sb(s->blas, RB_OP_T, RB_OP_N, fin, (int)rows, fout, &one, theta + w_off, fout, d, dz, fout, rows * fout, &zero, o, fin,
+                           rows * fin, E);
+    };
+    auto act_grad = [&](float *dh, const float *h, long long n) {
+      k_gemm_act_grad<<<dim3(blocks(n), E), 256, 0, st>>>(dh, h, n, act);
+    };
+    if (dW(g.k_f3, g.b_f3, 84, g.K, f2, Rc * 84, out, Rc)) return fail(MILE_ERR_HIP, "rocblas sgemm (d fc3) failed");
+    if (dX(g.k_f3, 84, g.K, out, Rc, df2)) return fail(MILE_ERR_HIP, "rocblas sgemm (d fc3 in) failed");
+    act_grad(df2, f2, Rc * 84);
+    if (dW(g.k_f2, g.b_f2, 120, 84, f1, Rc * 120, df2, Rc)) return fail(MILE_ERR_HIP, "rocblas sgemm (d fc2) failed");
+    if (dX(g.k_f2, 120, 84, df2, Rc, df1)) return fail(MILE_ERR_HIP, "rocblas sgemm (d fc2 in) failed");
+    act_grad(df1, f1, Rc * 120);
+    if (dW(g.k_f1, g.b_f1, g.flat, 120, p2, Rc * g.flat, df1, Rc)) return fail(MILE_ERR_HIP, "rocblas sgemm (d fc1) failed");
+    if (dX(g.k_f1, g.flat, 120, df1, Rc, dp2)) return fail(MILE_ERR_HIP, "rocblas sgemm (d fc1 in) failed");
+    k_unpool_actgrad<<<blocks(B * (long long)n_a2), 256, 0, st>>>(dp2, a2, dz2, B, g.h2, g.w2, 16, act);
+    if (dW(g.k_c2, g.b_c2, 150, 16, col2, M2 * 150, dz2, M2)) return fail(MILE_ERR_HIP, "rocblas sgemm (d conv2) failed");
+    if (dX(g.k_c2, 150, 16, dz2, M2, col2)) return fail(MILE_ERR_HIP, "rocblas sgemm (d conv2 in) failed");   // d(col2) over col2
+    k_col2im5<<<blocks(B * (long long)n_p1), 256, 0, st>>>(col2, dp1, B, g.h2, g.w2, 6);
+    k_unpool_actgrad<<<blocks(B * (long long)n_a1), 256, 0, st>>>(dp1, a1, dz1, B, g.H, g.W, 6, act);
+    if (dW(g.k_c1, g.b_c1, 25 * g.C, 6, col1, 0, dz1, M1)) return fail(MILE_ERR_HIP, "rocblas sgemm (d conv1) failed");
+  }
+  HIP_TRY(hipGetLastError());
+  return MILE_OK;
 }
 
 // Layer-wise path: per row chunk, forward GEMM + bias/activation per layer, head, then per layer
@@ -556,6 +719,9 @@ static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t s
     else if (nh == 2 && fq == 2) e = launch_w64<2, 2>(gp, E, st);
     else if (nh == 3 && fq == 2) e = launch_w64<3, 2>(gp, E, st);
     HIP_TRY(e);
+  } else if (kernel == MILE_GRAD_LENET_F32) {
+    const int rc = run_lenet(s, theta, E, gp.X, gp.y, s->N, gp.slabs, gp.dp, gp.llpart, nullptr, 0, st);
+    if (rc) return rc;
   } else if (kernel == MILE_GRAD_GEMM_F32) {
     const int rc = launch_grad_gemm(s, gp, E, st);
     if (rc) return rc;
@@ -664,6 +830,13 @@ extern "C" int32_t mile_pointwise_loglik(mile_sampler *s, const float *theta, in
   pp.spec = s->ds; pp.theta = theta; pp.X = s->ev_X; pp.Xp = s->ev_Xp; pp.y = s->ev_y; pp.out = out;
   pp.N = (int)N; pp.Npad = Npad; pp.Fp = Fp; pp.R = generic_R(s->ds);
   const int kernel = resolved_kernel(s);
+  if (kernel == MILE_GRAD_LENET_F32) {
+    for (int s0 = 0; s0 < S; s0 += 256) {
+      const int rc = run_lenet(s, theta + (size_t)s0 * s->ds.d, std::min(256, S - s0), s->ev_X, s->ev_y, (int)N, nullptr, 0, nullptr, out, s0, st);
+      if (rc) return rc;
+    }
+    return MILE_OK;
+  }
   if (kernel == MILE_GRAD_GEMM_F32 || (kernel == MILE_GRAD_MFMA_W128_BF16 && rocblas_load())) {
     // wide nets: evaluation stays fp32 whatever the sampling kernel was
     return launch_fwd_gemm(s, theta, S, s->ev_X, s->ev_y, (int)N, out, st);
@@ -707,6 +880,9 @@ int32_t mile_grad_launch_info(const mile_sampler *s, int32_t E, int32_t *grid_x,
     lds = nh == 1 ? (fq == 1 ? w64_lds_bytes<1, 1>() : w64_lds_bytes<1, 2>())
         : nh == 2 ? (fq == 1 ? w64_lds_bytes<2, 1>() : w64_lds_bytes<2, 2>())
                   : (fq == 1 ? w64_lds_bytes<3, 1>() : w64_lds_bytes<3, 2>());
+  } else if (kernel == MILE_GRAD_LENET_F32) {
+    nm = "rocblas_sgemm_strided_batched+k_im2col5/k_col2im5/k_avgpool2";
+    lds = 0;
   } else if (kernel == MILE_GRAD_GEMM_F32) {
     nm = "rocblas_sgemm_strided_batched+k_gemm_*";
     lds = 0;

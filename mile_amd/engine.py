@@ -11,7 +11,7 @@ from typing import NamedTuple
 import torch
 
 from mile_amd import _lib
-from mile_amd.spec import ModelSpec
+from mile_amd.spec import LeNetSpec, ModelSpec
 
 
 class IntegratorState(NamedTuple):
@@ -57,6 +57,8 @@ class Engine:
         self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
         cs = _lib.ModelSpecC()
         cs.in_features = spec.in_features
+        if isinstance(spec, LeNetSpec):
+            cs.model, cs.img_c, cs.img_h, cs.img_w = 1, spec.channels, spec.height, spec.width
         cs.n_layers = len(spec.hidden_structure)
         if cs.n_layers > _lib.MILE_MAX_LAYERS:
             raise ValueError(f'at most {_lib.MILE_MAX_LAYERS} layers')
@@ -90,6 +92,10 @@ class Engine:
 
     def set_data(self, X, y):
         X = _f32(X, self.device, name='X')
+        if isinstance(self.spec, LeNetSpec) and X.ndim == 4:      # [N, C, H, W] images -> rows of C*H*W
+            if tuple(X.shape[1:]) != (self.spec.channels, self.spec.height, self.spec.width):
+                raise ValueError(f'X must be [N, {self.spec.channels}, {self.spec.height}, {self.spec.width}], got {tuple(X.shape)}')
+            X = X.reshape(X.shape[0], -1)
         if X.ndim != 2 or X.shape[1] != self.spec.in_features:
             raise ValueError(f'X must be [N, {self.spec.in_features}], got {tuple(X.shape)}')
         y = torch.as_tensor(y, device=self.device)
@@ -294,6 +300,8 @@ class Engine:
         X = _f32(X, self.device, name='X')
         y = torch.as_tensor(y, device=self.device)
         y = (y.to(torch.float32) if self.spec.task == 'regr' else y.to(torch.int32)).contiguous()
+        if isinstance(self.spec, LeNetSpec) and X.ndim == 4:
+            X = X.reshape(X.shape[0], -1).contiguous()
         if X.ndim != 2 or X.shape[1] != self.spec.in_features or y.shape != (X.shape[0],):
             raise ValueError('X must be [N, F] and y [N]')
         out = torch.empty((th.shape[0], X.shape[0]), dtype=torch.float32, device=self.device)

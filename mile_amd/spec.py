@@ -69,3 +69,76 @@ class ModelSpec:
             out.append((f'{self.root}.layer{li}.kernel', off, (fin, fout)))
             off += fin * fout
         return out
+
+
+@dataclass(frozen=True)
+class LeNetSpec:
+    """LeNet (src/models/images/cnns.py:10-66, LeNetConfig src/config/models/cnns.py) on [N, C, H, W] images:
+    Conv(6, 5x5, pad 2) - act - avg_pool 2 - Conv(16, 5x5) - act - avg_pool 2 - Dense 120 - Dense 84 - Dense out_dim.
+    Duck-types ModelSpec where the host code needs it (in_features, n_params, leaves, task/prior fields)."""
+
+    channels: int
+    height: int
+    width: int
+    out_dim: int
+    activation: str = 'relu'
+    task: str = 'classification'
+    prior: str = 'StandardNormal'
+    prior_loc: float = 0.0
+    prior_scale: float = 1.0
+    use_bias: bool = True
+    root: str = 'core'   # name of the LeNetCore submodule inside LeNet (cnns.py:21-25)
+
+    def __post_init__(self):
+        if self.activation not in ACTIVATIONS:
+            raise NotImplementedError(f'activation {self.activation!r} (supported: {ACTIVATIONS})')
+        if self.task not in TASKS:
+            raise NotImplementedError(f'Likelihood computation for {self.task} not implemented')
+        if self.prior not in PRIORS:
+            raise NotImplementedError(f'Prior Distribution for {self.prior} is not yet implemented.')
+        if self.prior == 'StandardNormal':
+            object.__setattr__(self, 'prior_loc', 0.0)
+            object.__setattr__(self, 'prior_scale', 1.0)
+        if not self.use_bias:
+            raise NotImplementedError('use_bias=False is not supported')
+        if self.task == 'regr' and self.out_dim != 2:
+            raise ValueError('regression needs out_dim == 2 (mu, log sigma)')
+        if (self.height // 2 - 4) // 2 < 1 or (self.width // 2 - 4) // 2 < 1:
+            raise ValueError('image too small for LeNet')
+
+    @property
+    def in_features(self) -> int:
+        return self.channels * self.height * self.width
+
+    @property
+    def flat(self) -> int:
+        return ((self.height // 2 - 4) // 2) * ((self.width // 2 - 4) // 2) * 16
+
+    @property
+    def hidden_structure(self):          # only its last entry (the output width) is meaningful for LeNet
+        return (self.out_dim,)
+
+    def leaves(self):
+        """[(dotted name, offset, shape)] in ravel_pytree order: conv1, conv2, fc1, fc2, fc3; bias before kernel;
+        conv kernels [kh, kw, in, out] as flax stores them."""
+        shapes = [('conv1.bias', (6,)), ('conv1.kernel', (5, 5, self.channels, 6)),
+                  ('conv2.bias', (16,)), ('conv2.kernel', (5, 5, 6, 16)),
+                  ('fc1.bias', (120,)), ('fc1.kernel', (self.flat, 120)),
+                  ('fc2.bias', (84,)), ('fc2.kernel', (120, 84)),
+                  ('fc3.bias', (self.out_dim,)), ('fc3.kernel', (84, self.out_dim))]
+        out, off = [], 0
+        for name, sh in shapes:
+            out.append((f'{self.root}.{name}', off, sh))
+            n = 1
+            for v in sh:
+                n *= v
+            off += n
+        return out
+
+    @property
+    def n_params(self) -> int:
+        name, off, sh = self.leaves()[-1]
+        n = 1
+        for v in sh:
+            n *= v
+        return off + n

@@ -1,0 +1,94 @@
+"""LeNet target (BASELINE config 5) on the HIP path vs the NumPy oracle (-m gpu)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture(scope='module')
+def LN():
+    from oracle import lenet_oracle
+    return lenet_oracle
+
+
+def _engine(ospec, prob):
+    from mile_amd import LeNetSpec
+    from mile_amd.engine import Engine
+    spec = LeNetSpec(ospec.channels, ospec.height, ospec.width, ospec.out_dim, activation=ospec.activation, task=ospec.task,
+                     prior=ospec.prior, prior_loc=ospec.prior_loc, prior_scale=ospec.prior_scale)
+    assert spec.n_params == ospec.n_params
+    assert [(n, o, tuple(s)) for n, o, s in spec.leaves()] == [(n, o, tuple(s)) for n, o, s in ospec.leaves()]
+    return Engine(spec, torch.from_numpy(prob['X']), torch.from_numpy(prob['y']), device='cuda:0')
+
+
+def _relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+CASES = [
+    # C, H, W, out_dim, activation, task, prior, N, E
+    (1, 28, 28, 10, 'relu', 'classification', 'Normal', 37, 3),      # MNIST-shaped
+    (3, 32, 32, 10, 'relu', 'classification', 'Normal', 20, 4),      # CIFAR-shaped (config 5)
+    (2, 13, 17, 2, 'tanh', 'regr', 'Laplace', 9, 2),                 # odd sizes: pooling crops a row and a column
+    (1, 12, 12, 3, 'sigmoid', 'classification', 'Normal', 1, 1),     # smallest image, one row, one particle
+]
+
+
+@pytest.mark.parametrize('C,H,W,K,act,task,prior,N,E', CASES)
+def test_lenet_logpost_grad_matches_oracle(LN, C, H, W, K, act, task, prior, N, E):
+    ospec = LN.LeNetSpec(C, H, W, K, activation=act, task=task, prior=prior, prior_scale=0.7 if prior == 'Laplace' else 1.0)
+    prob = LN.synthetic_problem(ospec, N, E, seed=3)
+    lp_ref, g_ref = LN.logpost_and_grad(ospec, prob['theta0'].astype(np.float64), prob['X'], prob['y'])
+    eng = _engine(ospec, prob)
+    assert eng.grad_kernel == 'lenet_f32'
+    lp, g = eng.logpost_grad(torch.from_numpy(prob['theta0']))
+    torch.cuda.synchronize()
+    # fp32 accumulation vs fp64: 2e-5 relative to the largest entry, per parameter leaf
+    assert _relerr(lp.cpu().numpy(), lp_ref) < 2e-5
+    g = g.cpu().numpy()
+    for name, off, shape in ospec.leaves():
+        n = int(np.prod(shape))
+        assert _relerr(g[:, off:off + n], g_ref[:, off:off + n]) < 5e-5, name
+
+
+def test_lenet_image_chunks_accumulate(LN, monkeypatch):
+    monkeypatch.setenv('MILE_GEMM_ROWS', '4')
+    ospec = LN.LeNetSpec(3, 16, 20, 5)
+    prob = LN.synthetic_problem(ospec, 11, 3, seed=5)
+    lp_ref, g_ref = LN.logpost_and_grad(ospec, prob['theta0'].astype(np.float64), prob['X'], prob['y'])
+    lp, g = _engine(ospec, prob).logpost_grad(torch.from_numpy(prob['theta0']))
+    assert _relerr(lp.cpu().numpy(), lp_ref) < 2e-5
+    assert _relerr(g.cpu().numpy(), g_ref) < 5e-5
+
+
+def test_lenet_steps_and_pointwise_loglik_match_oracle(LN, oracle):
+    ospec = LN.LeNetSpec(1, 14, 14, 4)
+    N, E, T = 25, 3, 4
+    prob = LN.synthetic_problem(ospec, N, E, seed=9)
+    rng = np.random.default_rng(4)
+    d = ospec.n_params
+    z0 = rng.standard_normal((E, d)).astype(np.float32)
+    noise = rng.standard_normal((T, 2, E, d)).astype(np.float32)
+    f = lambda th: LN.logpost_and_grad(ospec, th, prob['X'], prob['y'])
+    st = oracle.mclmc_init(f, prob['theta0'].astype(np.float64), z0.astype(np.float64))
+    for i in range(T):
+        st, info = oracle.mclmc_step(f, st, prob['eps'].astype(np.float64), prob['L'].astype(np.float64),
+                                     noise[i, 0].astype(np.float64), noise[i, 1].astype(np.float64))
+    eng = _engine(ospec, prob)
+    s = eng.init(torch.from_numpy(prob['theta0']), noise=torch.from_numpy(z0))
+    s, info_g, _ = eng.step(s, torch.from_numpy(prob['eps']), torch.from_numpy(prob['L']), n_steps=T, noise=torch.from_numpy(noise))
+    torch.cuda.synchronize()
+    assert _relerr(s.position.cpu().numpy(), st.position) < 1e-4
+    assert _relerr(s.logdensity.cpu().numpy(), st.logdensity) < 1e-5
+    assert _relerr(s.logdensity_grad.cpu().numpy(), st.logdensity_grad) < 1e-3
+    assert np.abs(info_g.energy_change[-1].cpu().numpy() - info.energy_change).max() < 5e-3
+    # evaluation path: per-row log-likelihood of held-out images
+    test = LN.synthetic_problem(ospec, 13, 1, seed=10)
+    out = LN.forward(ospec, prob['theta0'].astype(np.float64), test['X'])
+    ref, _ = oracle.pointwise_loglik_raw(ospec, out, test['y'])
+    pw = eng.pointwise_loglik(torch.from_numpy(prob['theta0']), torch.from_numpy(test['X']), torch.from_numpy(test['y']))
+    assert pw.shape == (E, 13)
+    assert np.abs(pw.cpu().numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
