@@ -86,7 +86,9 @@ typedef struct mile_model_spec {
   int32_t model;                     /* mile_model.  LENET: X rows are NCHW images, in_features = C*H*W,
                                       * n_layers = 1 and widths[0] = out_dim; parameter order is ravel_pytree's
                                       * (conv1, conv2, fc1, fc2, fc3; bias before kernel [kh,kw,in,out]) */
-  int32_t img_c, img_h, img_w;       /* LENET image geometry (ignored for the FCN) */
+  int32_t img_c;                     /* LENET image geometry (ignored for the FCN) */
+  int32_t img_h;
+  int32_t img_w;
 } mile_model_spec;
 
 /* blackjax IntegratorState(position, momentum, logdensity, logdensity_grad) for an
