@@ -32,6 +32,8 @@ def _from_dict(cls, data: dict, path: str = ''):
     for k, v in data.items():
         f = names[k]
         sub = _NESTED.get((cls.__name__, k))
+        if sub is not None and not isinstance(sub, type):
+            sub = sub(v)                      # dispatch on the mapping's content (model family)
         kw[k] = _from_dict(sub, v, f'{path}.{k}' if path else k) if sub is not None and v is not None else v
     missing = [n for n, f in names.items() if n not in kw and f.default is dataclasses.MISSING
                and f.default_factory is dataclasses.MISSING]
@@ -86,6 +88,32 @@ class FCNConfig:
                'hidden_structure must be a list of positive ints')
         _check(self.activation in ('sigmoid', 'relu', 'gelu', 'tanh', 'softmax', 'leaky_relu'),
                f'unknown activation {self.activation!r}')
+
+
+@dataclass(frozen=True)
+class LeNetConfig:
+    """src/config/models/cnns.py:7-24."""
+
+    model: str = 'LeNet'
+    activation: str = 'sigmoid'
+    out_dim: int = 10
+    use_bias: bool = True
+
+    def __post_init__(self):
+        _check(self.model == 'LeNet', f'Could not find model {self.model}.')
+        _check(self.activation in ('sigmoid', 'relu', 'gelu', 'tanh', 'softmax', 'leaky_relu'),
+               f'unknown activation {self.activation!r}')
+        _check(isinstance(self.out_dim, int) and self.out_dim > 0, 'out_dim must be a positive int')
+
+
+def _model_config(data):
+    """ModelConfig.from_dict dispatch on the `model` key (src/config/models/__init__.py)."""
+    name = data.get('model', 'FCN') if isinstance(data, dict) else 'FCN'
+    if name == 'LeNet':
+        return LeNetConfig
+    if name == 'FCN':
+        return FCNConfig
+    raise ConfigError(f"Could not find model {name}. Available on the MI355X hot path: ['FCN', 'LeNet']")
 
 
 @dataclass(frozen=True)
@@ -189,7 +217,7 @@ class Config:
 
     experiment_name: str
     data: DataConfig
-    model: FCNConfig
+    model: Any
     training: TrainingConfig = field(default_factory=TrainingConfig)
     saving_dir: str = 'results/'
     rng: int = 42
@@ -255,7 +283,7 @@ class Config:
 
 _NESTED = {
     ('Config', 'data'): DataConfig,
-    ('Config', 'model'): FCNConfig,
+    ('Config', 'model'): _model_config,
     ('Config', 'training'): TrainingConfig,
     ('TrainingConfig', 'warmstart'): WarmStartConfig,
     ('TrainingConfig', 'sampler'): SamplerConfig,

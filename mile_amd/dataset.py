@@ -72,3 +72,41 @@ class TabularLoader:
 
     def __len__(self):
         return len(self.data)
+
+
+class ImageLoader:
+    """Image data for the LeNet target (mirror of src/dataset/image.py's role: [N, C, H, W] float32 images and
+    integer labels, split into train / valid / test).  Only ``source: synthetic`` (path = '<N>x<C>x<H>x<W>',
+    10 classes) and local ``.npz`` files with arrays ``x`` [N, C, H, W] and ``y`` [N] are available: the
+    reference's torchvision download (image.py:161-173) needs the network."""
+
+    def __init__(self, config: DataConfig, rng: int, shuffle: bool = True):
+        assert config.data_type == 'image'
+        self.config = config
+        g = np.random.Generator(np.random.PCG64(rng))
+        if config.source == 'synthetic':
+            N, C, H, W = (int(v) for v in config.path.lower().split('x'))
+            x = g.standard_normal((N, C, H, W)).astype(np.float32)
+            proto = g.standard_normal((10, C, H, W)).astype(np.float32)           # class prototypes
+            y = g.integers(0, 10, N)
+            x = (x + 0.5 * proto[y]).astype(np.float32)
+        elif str(config.path).endswith('.npz'):
+            z = np.load(config.path)
+            x, y = np.asarray(z['x'], dtype=np.float32), np.asarray(z['y'])
+        else:
+            raise NotImplementedError('image data: only source "synthetic" or a local .npz with x [N,C,H,W], y [N]')
+        if config.normalize:
+            x = (x - x.mean()) / x.std()
+        if shuffle:
+            perm = g.permutation(len(x))
+            x, y = x[perm], y[perm]
+        if config.datapoint_limit:
+            x, y = x[: config.datapoint_limit], y[: config.datapoint_limit]
+        y = y.astype(np.int32) if config.task == 'class' else y.astype(np.float32)
+        n = len(x)
+        a, b = int(n * config.train_split), int(n * (config.train_split + config.valid_split))
+        self.train_x, self.valid_x, self.test_x = x[:a], x[a:b], x[b:]
+        self.train_y, self.valid_y, self.test_y = y[:a], y[a:b], y[b:]
+
+    def __len__(self):
+        return len(self.train_x) + len(self.valid_x) + len(self.test_x)

@@ -7,12 +7,13 @@ Python, so a bound target can cross the C ABI (SURVEY 8b "Factory").
 """
 from __future__ import annotations
 
+import dataclasses
 from functools import partial
 
 import torch
 
 from mile_amd.priors import Prior
-from mile_amd.spec import ModelSpec
+from mile_amd.spec import LeNetSpec, ModelSpec
 
 TASK_ALIASES = {'regr': 'regr', 'regression': 'regr', 'class': 'classification', 'classification': 'classification'}
 
@@ -28,15 +29,18 @@ class ProbabilisticModel:
         task = TASK_ALIASES[str(task)]
         if n_batches != 1:
             raise NotImplementedError('Mini-Batch Sampling not yet implemented.')  # trainer.py:591-592
-        if isinstance(module, ModelSpec):
+        if isinstance(module, LeNetSpec):
+            self.spec = dataclasses.replace(module, task=task, prior=prior.name, prior_loc=prior.loc, prior_scale=prior.scale)
+        if isinstance(module, (ModelSpec, LeNetSpec)):
             base = module
         else:
             base = ModelSpec(in_features=module.in_features, hidden_structure=tuple(module.hidden_structure),
                              activation=str(getattr(module.activation, 'value', module.activation)),
                              use_bias=getattr(module, 'use_bias', True))
-        self.spec = ModelSpec(in_features=base.in_features, hidden_structure=base.hidden_structure,
-                              activation=base.activation, task=task, prior=prior.name,
-                              prior_loc=prior.loc, prior_scale=prior.scale, use_bias=base.use_bias)
+        if not isinstance(module, LeNetSpec):
+            self.spec = ModelSpec(in_features=base.in_features, hidden_structure=base.hidden_structure,
+                                  activation=base.activation, task=task, prior=prior.name,
+                                  prior_loc=prior.loc, prior_scale=prior.scale, use_bias=base.use_bias)
         self.task = task
         self.module = module
         self.n_params = self.spec.n_params

@@ -20,10 +20,10 @@ import torch
 from mile_amd import distributed as mdist
 from mile_amd.callbacks import load_params_batch, save_params, save_tree
 from mile_amd.config import Config
-from mile_amd.dataset import TabularLoader
+from mile_amd.dataset import ImageLoader, TabularLoader
 from mile_amd.probabilistic import ProbabilisticModel
 from mile_amd.sampling import inference_loop
-from mile_amd.spec import ModelSpec
+from mile_amd.spec import LeNetSpec, ModelSpec
 from mile_amd.tree import PRNGKey
 
 logger = logging.getLogger(__name__)
@@ -56,13 +56,21 @@ class BDETrainer:
         # reproduces the reference's sequential chain groups when set
         self.n_devices = chains_per_group or self.n_chains
         self.train_plan = train_plan(self.n_chains, self.n_devices)
-        if config.data.data_type != 'tabular':
-            raise NotImplementedError('only tabular data is on the MI355X hot path')
-        self.loader = TabularLoader(config.data, rng=config.rng, target_len=config.data.target_len)
-        F = self.loader.train_x.shape[-1]
-        self.spec_model = ModelSpec(in_features=F, hidden_structure=tuple(config.model.hidden_structure),
-                                    activation=config.model.activation,
-                                    task='regr' if config.data.task == 'regr' else 'classification')
+        task = 'regr' if config.data.task == 'regr' else 'classification'
+        if config.model.model == 'LeNet':
+            if config.data.data_type != 'image':
+                raise ValueError('model LeNet needs data_type: image')
+            self.loader = ImageLoader(config.data, rng=config.rng)
+            _, C, H, W = self.loader.train_x.shape
+            self.spec_model = LeNetSpec(channels=C, height=H, width=W, out_dim=config.model.out_dim,
+                                        activation=config.model.activation, task=task)
+        else:
+            if config.data.data_type != 'tabular':
+                raise NotImplementedError('the FCN runs on tabular data; image data goes with model LeNet')
+            self.loader = TabularLoader(config.data, rng=config.rng, target_len=config.data.target_len)
+            F = self.loader.train_x.shape[-1]
+            self.spec_model = ModelSpec(in_features=F, hidden_structure=tuple(config.model.hidden_structure),
+                                        activation=config.model.activation, task=task)
         self.prob_model = ProbabilisticModel(module=self.spec_model, prior=config.training.sampler.prior,
                                              task=config.data.task, n_batches=1,
                                              grad_kernel=config.training.sampler.grad_kernel)
@@ -90,7 +98,8 @@ class BDETrainer:
                     w = torch.empty(shape, dtype=torch.float32)
                     torch.nn.init.trunc_normal_(w, mean=0.0, std=1.0, a=-2.0, b=2.0, generator=g)
                     # variance_scaling(1.0, 'fan_in', 'truncated_normal'): std = sqrt(1/fan_in) / 0.87962566...
-                    flat[off:off + w.numel()] = (w * (math.sqrt(1.0 / shape[0]) / 0.87962566103423978)).reshape(-1)
+                    fan_in = int(np.prod(shape[:-1]))             # Dense: in; Conv: kh * kw * in
+                    flat[off:off + w.numel()] = (w * (math.sqrt(1.0 / fan_in) / 0.87962566103423978)).reshape(-1)
             rows.append(flat.numpy())
         return np.stack(rows).astype(np.float32)
 
@@ -121,7 +130,7 @@ class BDETrainer:
             if warm_path.exists():
                 chains = sorted((warm_path / i for i in os.listdir(warm_path) if i.startswith('params')),
                                 key=lambda p: int(p.stem.split('_')[-1]))
-            x = torch.from_numpy(np.ascontiguousarray(self.loader.train_x))
+            x = torch.from_numpy(np.ascontiguousarray(self.loader.train_x).reshape(len(self.loader.train_x), -1))
             y = torch.from_numpy(np.ascontiguousarray(self.loader.train_y))
             log_post = self.prob_model.bind(x, y)
             for step in self.train_plan:

@@ -92,3 +92,28 @@ def test_lenet_steps_and_pointwise_loglik_match_oracle(LN, oracle):
     pw = eng.pointwise_loglik(torch.from_numpy(prob['theta0']), torch.from_numpy(test['X']), torch.from_numpy(test['y']))
     assert pw.shape == (E, 13)
     assert np.abs(pw.cpu().numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_train_cli_lenet_yaml(tmp_path):
+    """The YAML surface with `model: LeNet` and image data (config 5 shape, scaled down)."""
+    import subprocess, sys, yaml
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    cfg = yaml.safe_load((root / 'experiments' / 'mclmc_cifar_lenet_b5.yaml').read_text())
+    cfg['saving_dir'] = str(tmp_path)
+    cfg['experiment_name'] = 'lenet_small'
+    cfg['data']['path'] = '300x3x16x16'
+    cfg['training']['sampler'].update(warmup_steps=200, n_samples=20, n_chains=3, desired_energy_var_start=5e-4,
+                                      desired_energy_var_end=1e-4)
+    (tmp_path / 'cfg.yaml').write_text(yaml.safe_dump(cfg))
+    r = subprocess.run([sys.executable, str(root / 'train.py'), '-c', str(tmp_path / 'cfg.yaml'), '-d', '1'],
+                       capture_output=True, text=True, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    exp = tmp_path / 'lenet_small'
+    assert sorted(p.name for p in (exp / 'samples').iterdir() if p.is_dir()) == ['0', '1', '2']
+    z = np.load(exp / 'samples' / '2' / 'sample_10.npz')
+    assert z.files == ['core.conv1.bias', 'core.conv1.kernel', 'core.conv2.bias', 'core.conv2.kernel', 'core.fc1.bias',
+                       'core.fc1.kernel', 'core.fc2.bias', 'core.fc2.kernel', 'core.fc3.bias', 'core.fc3.kernel']
+    assert z['core.conv1.kernel'].shape == (5, 5, 3, 6) and z['core.conv2.kernel'].shape == (5, 5, 6, 16)
+    assert z['core.fc1.kernel'].shape == (2 * 2 * 16, 120) and z['core.fc3.bias'].shape == (10,)
+    assert all(np.isfinite(z[k]).all() for k in z.files)
