@@ -174,6 +174,57 @@ def test_random_chain_init_follows_flax_dense_defaults(tmp_path):
             assert np.abs(v).max() <= 2.0 * sd / 0.87962566103423978 + 1e-6
 
 
+def test_lenet_spec_config_and_image_loader(tmp_path):
+    """Host side of the LeNet target: parameter layout == the oracle's (ravel_pytree order), YAML dispatch on
+    `model`, synthetic / npz image loading and splits, flax-style conv initialisation (fan_in = kh*kw*in)."""
+    import yaml
+    from mile_amd import LeNetSpec
+    from mile_amd.config import Config, ConfigError, DataConfig
+    from mile_amd.dataset import ImageLoader
+    from mile_amd.trainer import BDETrainer
+    from mile_amd.tree import ravel_tree, unravel_tree
+    from oracle import lenet_oracle as LN
+    sp, osp = LeNetSpec(3, 32, 32, 10), LN.LeNetSpec(3, 32, 32, 10)
+    assert sp.n_params == osp.n_params == 83126 and sp.in_features == 3072 and sp.flat == 576
+    assert [(n, o, tuple(s)) for n, o, s in sp.leaves()] == [(n, o, tuple(s)) for n, o, s in osp.leaves()]
+    flat = torch.arange(2 * sp.n_params, dtype=torch.float32).reshape(2, -1)
+    tree = unravel_tree(sp, flat)
+    assert list(tree) == ['core'] and list(tree['core']) == ['conv1', 'conv2', 'fc1', 'fc2', 'fc3']
+    assert tree['core']['conv1']['kernel'].shape == (2, 5, 5, 3, 6)
+    assert torch.equal(ravel_tree(sp, tree), flat)
+    with pytest.raises(ValueError):
+        LeNetSpec(1, 11, 28, 10)                        # (11 // 2 - 4) // 2 == 0
+    cfg = Config.from_file(ROOT / 'experiments' / 'mclmc_cifar_lenet_b5.yaml')
+    assert type(cfg.model).__name__ == 'LeNetConfig' and cfg.model.out_dim == 10 and cfg.data.data_type == 'image'
+    d = cfg.to_dict()
+    d['model']['model'] = 'ResNet'
+    with pytest.raises(ConfigError, match='Could not find model'):
+        Config.from_dict(d)
+    dc = DataConfig(path='40x2x12x14', source='synthetic', data_type='image', task='class', normalize=True,
+                    train_split=0.5, valid_split=0.25, test_split=0.25)
+    ld = ImageLoader(dc, rng=3)
+    assert ld.train_x.shape == (20, 2, 12, 14) and ld.valid_x.shape == (10, 2, 12, 14) and ld.test_y.shape == (10,)
+    assert ld.train_y.dtype == np.int32 and 0 <= ld.train_y.min() and ld.train_y.max() < 10 and ld.train_x.dtype == np.float32
+    np.savez(tmp_path / 'img.npz', x=np.ones((8, 1, 12, 12), np.float32), y=np.arange(8) % 3)
+    l2 = ImageLoader(DataConfig(path=str(tmp_path / 'img.npz'), source='local', data_type='image', task='class',
+                                train_split=0.5, valid_split=0.25, test_split=0.25), rng=0)
+    assert l2.train_x.shape == (4, 1, 12, 12) and len(l2) == 8
+    y = yaml.safe_load((ROOT / 'experiments' / 'mclmc_cifar_lenet_b5.yaml').read_text())
+    y['saving_dir'] = str(tmp_path)
+    y['data']['path'] = '30x3x16x16'
+    (tmp_path / 'c.yaml').write_text(yaml.safe_dump(y))
+    tr = BDETrainer(Config.from_file(tmp_path / 'c.yaml'))
+    assert tr.prob_model.spec.task == 'classification' and tr.prob_model.spec.flat == 64
+    w = tr.init_module_params([0])
+    for name, off, shape in tr.prob_model.spec.leaves():
+        v = w[0, off:off + int(np.prod(shape))]
+        if name.endswith('bias'):
+            assert not v.any()
+        else:
+            fan_in = int(np.prod(shape[:-1]))
+            assert np.abs(v).max() <= 2.0 * math.sqrt(1.0 / fan_in) / 0.87962566103423978 + 1e-6 and v.std() > 0
+
+
 def test_train_plan_matches_reference_semantics():
     from mile_amd.sampling import kept_indices
     from mile_amd.trainer import train_plan
