@@ -60,6 +60,10 @@ __device__ __forceinline__ float bf16_colsum(const bf16x8 v, float acc) {   // a
   return acc;
 }
 
+// Workgroup barrier for LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the global
+// prefetches (X, y of the next tile pair) that are deliberately in flight across it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
@@ -92,7 +96,7 @@ __device__ __forceinline__ void store_group_masked(char *dst, const f32x4_t v, c
   *reinterpret_cast<f32x2_t *>(dst) = o;
 }
 
-template <int NH, int RT>
+template <int NH, int RT, bool TIMING = false>
 __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
   using LY = W128Layout<NH, RT>;
   extern __shared__ __attribute__((aligned(16))) char lds128[];
@@ -176,12 +180,50 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
       for (int ib = 0; ib < 4; ++ib) dW[l][ib][j] = 0.0f;
   }
   float ll_acc = 0.0f;
+  long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;   // TIMING: cycles per phase (dev builds only)
+  auto tick = [&](int k) {
+    if (TIMING) {
+      const long long now = __builtin_readcyclecounter();
+      tph[k] += now - tlast;
+      tlast = now;
+    }
+  };
+  if (TIMING) tlast = __builtin_readcyclecounter();
 
   const int NBS = p.Npb / (32 * RT);   // super tiles of RT row tiles
   const int nb0 = (int)((long long)sidx * NBS / p.S), nb1 = (int)((long long)(sidx + 1) * NBS / p.S);
 
+  // Global operands are fetched a phase (X: an iteration) ahead of their use: with one wave per SIMD a global
+  // load issued where it is needed costs its full ~2000-cycle latency every tile pair.
+  bf16x8 xb_next[RT];
+#pragma unroll
+  for (int q = 0; q < RT; ++q) {
+    const int rowc = 32 * (nb0 < nb1 ? nb0 * RT + q : 0);
+    xb_next[q] = *reinterpret_cast<const bf16x8 *>(Xb + (size_t)(rowc + r) * 16 + 8 * h);
+  }
   for (int t = nb0; t < nb1; ++t) {
+    bf16x8 xb_cur[RT], xt_cur[RT][2];
+    float y_cur[RT];
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+      xb_cur[q] = xb_next[q];
+      y_cur[q] = 0.0f;
+    }
+    // X of the next tile pair and X^T of this one are requested two phases before their use (not at the top:
+    // 24 registers held for a whole iteration spill)
+    auto prefetch_x = [&]() {
+#pragma unroll
+      for (int q = 0; q < RT; ++q) {
+        const int row0 = 32 * (t * RT + q);
+        const int rown = 32 * ((t + 1 < nb1 ? t + 1 : t) * RT + q);
+        xb_next[q] = *reinterpret_cast<const bf16x8 *>(Xb + (size_t)(rown + r) * 16 + 8 * h);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          xt_cur[q][s] = *reinterpret_cast<const bf16x8 *>(Xt + (size_t)r * p.Npb + row0 + 16 * s + 8 * h);
+      }
+    };
     f32x16 acc[RT];
+    bf16x8 afp[8];   // weight fragments of the NEXT phase, read before the barrier that precedes it (they do not depend on it)
     // ---- forward ---------------------------------------------------------------------------
 #pragma unroll
     for (int l = 0; l < NH; ++l) {
@@ -189,28 +231,30 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
         const f32x16 b0 = bias_tile(0);
 #pragma unroll
         for (int q = 0; q < RT; ++q) {
+          acc[q] = mfma_bf16(w1frag, xb_cur[q], b0);
+        }
+#pragma unroll
+        for (int q = 0; q < RT; ++q) {   // targets: needed three phases from here
           const int row0 = 32 * (t * RT + q);
-          const bf16x8 xb = *reinterpret_cast<const bf16x8 *>(Xb + (size_t)(row0 + r) * 16 + 8 * h);
-          acc[q] = mfma_bf16(w1frag, xb, b0);
+          y_cur[q] = yv[row0 + r < p.N ? row0 + r : 0];
         }
       } else {
         const char *Wimg = lds + LY::WIMG + (l - 1) * 32768;
         // all fragment reads of the phase are issued before the first MFMA: with one wave per SIMD nothing
         // else hides the LDS latency, and read-then-use pairs would pay it once per MFMA
-        bf16x8 af[8], bfr[RT][8];
+        bf16x8 bfr[RT][8];
         const f32x16 bl = bias_tile(l);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          af[s] = tr_frag(Wimg, 16 * s, 32 * w, lane);
+        for (int s = 0; s < 8; ++s)
 #pragma unroll
           for (int q = 0; q < RT; ++q)
             bfr[q][s] = row_frag(lds + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + (l - 1) * 8192, r, 2 * s + h);
-        }
         __builtin_amdgcn_sched_barrier(0);   // keep the reads above, the MFMAs below
 #pragma unroll
         for (int s = 0; s < 8; ++s)
 #pragma unroll
-          for (int q = 0; q < RT; ++q) acc[q] = mfma_bf16(af[s], bfr[q][s], s == 0 ? bl : acc[q]);
+          for (int q = 0; q < RT; ++q) acc[q] = mfma_bf16(afp[s], bfr[q][s], s == 0 ? bl : acc[q]);
+        (void)Wimg;
       }
 #pragma unroll
       for (int q = 0; q < RT; ++q) {
@@ -230,7 +274,13 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
           }
         }
       }
-      __syncthreads();
+      if (l + 1 < NH) {   // weights of layer l + 1 (image l), forward form
+#pragma unroll
+        for (int s = 0; s < 8; ++s) afp[s] = tr_frag(lds + LY::WIMG + l * 32768, 16 * s, 32 * w, lane);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      lds_barrier();
+      tick(l);
     }
     // ---- head + backward through it: every wave sums the partials and evaluates the likelihood for its
     // lanes' rows; d(out) feeds dH straight from registers, and, transposed through a private 128-byte
@@ -254,6 +304,7 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) ah[q][s] = tr_frag(Hin, 16 * s, 32 * w, lane);
       }
+      if (NH == 1) prefetch_x();
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < RT; ++q) {
@@ -262,7 +313,7 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
         const float sr = ((pr[q][0][1] + pr[q][1][1]) + (pr[q][2][1] + pr[q][3][1])) + bo1;
         float dmu = 0.0f, dsg = 0.0f;
         if (h == 0 && row0 + r < p.N) {
-          const float ll = row_loss_regr(mu, sr, yv[row0 + r], dmu, dsg);
+          const float ll = row_loss_regr(mu, sr, y_cur[q], dmu, dsg);
           ll_acc += ll;
         }
         bf16x8 bdo;
@@ -293,8 +344,14 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
           store_group_masked(ts + LY::DZ + offg[g], v, hm[q][g]);
         }
       }
+      if (NH >= 2) {   // weights of the last hidden layer, backward form
+#pragma unroll
+        for (int s = 0; s < 8; ++s) afp[s] = row_frag(lds + LY::WIMG + (NH - 2) * 32768, 32 * w + r, 2 * s + h);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-    __syncthreads();
+    lds_barrier();
+    tick(3);
     // ---- backward: hidden layers NH .. 2 ------------------------------------------------------------
     // Pinned order (sched_barrier fences): all dH operands are read first; the transposed dW operands
     // are read between the dH MFMAs as those release registers; the dZ epilogue of the dH result runs
@@ -306,18 +363,17 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
       f32x16 zero16;
 #pragma unroll
       for (int j = 0; j < 16; ++j) zero16[j] = 0.0f;
-      bf16x8 af[8], bfr[RT][8], bq[RT][2], ah[RT][2][4];
+      bf16x8 bfr[RT][8], bq[RT][2], ah[RT][2][4];
       f32x2_t hm[RT][4];
       int offg[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) offg[g] = img_off(r, 4 * w + g) + 8 * h;
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        af[s] = row_frag(Wimg, 32 * w + r, 2 * s + h);
+      for (int s = 0; s < 8; ++s)
 #pragma unroll
         for (int q = 0; q < RT; ++q)
           bfr[q][s] = row_frag(lds + LY::TILE + q * LY::TILE_BYTES + LY::DZ + pp * 8192, r, 2 * s + h);
-      }
+      (void)Wimg;
 #pragma unroll
       for (int q = 0; q < RT; ++q)
 #pragma unroll
@@ -327,7 +383,7 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
 #pragma unroll
-        for (int q = 0; q < RT; ++q) acc[q] = mfma_bf16(af[s], bfr[q][s], s == 0 ? zero16 : acc[q]);
+        for (int q = 0; q < RT; ++q) acc[q] = mfma_bf16(afp[s], bfr[q][s], s == 0 ? zero16 : acc[q]);
         {
           const int q = (s * RT) / 8, sub = RT == 2 ? (s & 3) : (s >> 1);   // RT = 1: four steps carry reads
           const char *ts = lds + LY::TILE + q * LY::TILE_BYTES;
@@ -339,6 +395,10 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
             if (sub == 3) { ah[q][1][2] = tr_frag(Hin, 16, 64, lane); ah[q][1][3] = tr_frag(Hin, 16, 96, lane); }
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (l == 1) {   // the dH operands are consumed: their registers take the global prefetch
+        prefetch_x();
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
@@ -360,7 +420,13 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
         }
       }
       pp ^= 1;
-      __syncthreads();
+      if (l >= 2) {   // weights of the next layer down, backward form
+#pragma unroll
+        for (int s = 0; s < 8; ++s) afp[s] = row_frag(lds + LY::WIMG + (l - 2) * 32768, 32 * w + r, 2 * s + h);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      lds_barrier();
+      tick(3 + l);
     }
     // ---- backward: first layer ------------------------------------------------------------------------
 #pragma unroll
@@ -370,12 +436,16 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const bf16x8 bq = tr_frag(dz, 16 * s, 32 * w, lane);
-        const bf16x8 xt = *reinterpret_cast<const bf16x8 *>(Xt + (size_t)r * p.Npb + row0 + 16 * s + 8 * h);
-        dW1 = mfma_bf16(xt, bq, dW1);
+        dW1 = mfma_bf16(xt_cur[q][s], bq, dW1);
         db[0] = bf16_colsum(bq, db[0]);
       }
     }
+    tick(6);
   }
+  if (TIMING && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+    printf("w128b phase cycles per tile pair (%d pairs): F1 %lld F2 %lld F3 %lld headbwd %lld L(1) %lld L(2) %lld first %lld\n", nb1 - nb0,
+           tph[0] / (nb1 - nb0), tph[1] / (nb1 - nb0), tph[2] / (nb1 - nb0), tph[3] / (nb1 - nb0), tph[4] / (nb1 - nb0),
+           tph[5] / (nb1 - nb0), tph[6] / (nb1 - nb0));
 
   // ---- write this workgroup's slab: every parameter is owned by exactly one lane ----------------------
 #pragma unroll

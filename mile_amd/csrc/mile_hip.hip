@@ -465,6 +465,16 @@ static hipError_t launch_w128b(const GradParams &gp, int E, hipStream_t st) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
+  if (gp.dbg & 16) {   // dev: per-phase cycle counts from workgroup 0 (MILE_DEBUG=16)
+    static bool attr_t = false;
+    if (!attr_t) {
+      hipError_t e = hipFuncSetAttribute((const void *)k_grad_w128b<NH, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LY::BYTES);
+      if (e != hipSuccess) return e;
+      attr_t = true;
+    }
+    k_grad_w128b<NH, 2, true><<<dim3(gp.S, E), 256, LY::BYTES, st>>>(gp);
+    return hipGetLastError();
+  }
   k_grad_w128b<NH, 2><<<dim3(gp.S, E), 256, LY::BYTES, st>>>(gp);
   return hipGetLastError();
 }
