@@ -128,6 +128,8 @@ __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p) {
 #pragma unroll
   for (int c = 0; c < FP; ++c) w1acc[0][c] = w1acc[1][c] = 0.0f;
   float woacc[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+  // (the compiler keeps these three in scratch and read-modify-writes them once per block; measured: cheaper
+  // than ds_add_f32 accumulators in LDS, 90.2 vs 91.8 us per launch)
   float boacc[2] = {0.0f, 0.0f};
   float llacc = 0.0f;
 
@@ -160,14 +162,22 @@ __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p) {
     }
   };
   const int nblk = b1 - b0, nfull = nblk >> 2, rem = nblk & 3;
+  f32x4 xv_pre[FQ];   // X tile of the next full round, requested one block ahead
+#pragma unroll
+  for (int q = 0; q < FQ; ++q)
+    xv_pre[q] = *(const f32x4 *)(p.Xp + (size_t)((b0 + (nfull ? wave : 0)) * 32 + j) * FP + 8 * q + 4 * h);
   for (int r = 0; r < nfull; ++r) {
     const int row0 = (b0 + 4 * r + wave) * 32;
+    const int row_next = (b0 + 4 * (r + 1 < nfull ? r + 1 : r) + wave) * 32;
 #define W64_COOP 0
 #define W64_W 0
+#define W64_PREF 1
 #include "mile_grad_w64_block.inc"
 #undef W64_COOP
 #undef W64_W
+#undef W64_PREF
   }
+#define W64_PREF 0
   if (rem == 3) {               // three leftovers: one more independent round
     if (wave < 3) {
       const int row0 = (b0 + 4 * nfull + wave) * 32;
