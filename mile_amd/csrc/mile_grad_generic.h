@@ -22,6 +22,7 @@ struct GradParams {
   int32_t N, Npad, Fp, S, R;
   int32_t Npb;
   int32_t dp;           // slab row stride: d rounded up to a multiple of 4 floats (128-bit stores)
+  long long *dbg_buf;   // dev: 8 per-phase cycle counters (k_grad_w128b, MILE_DEBUG=16)
   int32_t dbg;          // debug knobs (MILE_DEBUG env): bit0 skip row blocks, bit1 skip staging, bit2 skip reduction
 };
 

@@ -64,6 +64,21 @@ __device__ __forceinline__ float bf16_colsum(const bf16x8 v, float acc) {   // a
 // prefetches (X, y of the next tile pair) that are deliberately in flight across it.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// row_loss_regr with the hardware exp / log / reciprocal (1 ulp-class, ~1e-6 relative): the head sits alone on
+// the critical path between two barriers, and next to bf16 operands (2^-9) the difference is invisible.
+__device__ __forceinline__ float row_loss_regr_fast(float mu, float sr, float yv, float &dmu, float &ds) {
+  const float es = __expf(sr);
+  const float sig = fminf(fmaxf(es, 1e-6f), 1e6f);
+  const bool unclipped = (es > 1e-6f) && (es < 1e6f);
+  const float isig = __frcp_rn(sig);
+  const float r = (yv - mu) * isig;
+  float ll = -0.5f * r * r - __logf(sig) - 0.91893853320467274f;
+  dmu = r * isig;
+  ds = unclipped ? (r * r - 1.0f) : 0.0f;
+  if (isnan(ll) || isnan(es) || isnan(mu)) { ll = 0.0f; dmu = 0.0f; ds = 0.0f; }
+  return ll;
+}
+
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
@@ -180,15 +195,15 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
       for (int ib = 0; ib < 4; ++ib) dW[l][ib][j] = 0.0f;
   }
   float ll_acc = 0.0f;
-  long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;   // TIMING: cycles per phase (dev builds only)
+  unsigned tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;   // TIMING: cycles per phase (dev builds only; wave-uniform -> SGPRs)
   auto tick = [&](int k) {
     if (TIMING) {
-      const long long now = __builtin_readcyclecounter();
+      const unsigned now = (unsigned)__builtin_readcyclecounter();
       tph[k] += now - tlast;
       tlast = now;
     }
   };
-  if (TIMING) tlast = __builtin_readcyclecounter();
+  if (TIMING) tlast = (unsigned)__builtin_readcyclecounter();
 
   const int NBS = p.Npb / (32 * RT);   // super tiles of RT row tiles
   const int nb0 = (int)((long long)sidx * NBS / p.S), nb1 = (int)((long long)(sidx + 1) * NBS / p.S);
@@ -313,7 +328,7 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
         const float sr = ((pr[q][0][1] + pr[q][1][1]) + (pr[q][2][1] + pr[q][3][1])) + bo1;
         float dmu = 0.0f, dsg = 0.0f;
         if (h == 0 && row0 + r < p.N) {
-          const float ll = row_loss_regr(mu, sr, y_cur[q], dmu, dsg);
+          const float ll = row_loss_regr_fast(mu, sr, y_cur[q], dmu, dsg);
           ll_acc += ll;
         }
         bf16x8 bdo;
@@ -442,11 +457,11 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
     }
     tick(6);
   }
-  if (TIMING && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
-    printf("w128b phase cycles per tile pair (%d pairs): F1 %lld F2 %lld F3 %lld headbwd %lld L(1) %lld L(2) %lld first %lld\n", nb1 - nb0,
-           tph[0] / (nb1 - nb0), tph[1] / (nb1 - nb0), tph[2] / (nb1 - nb0), tph[3] / (nb1 - nb0), tph[4] / (nb1 - nb0),
-           tph[5] / (nb1 - nb0), tph[6] / (nb1 - nb0));
-
+  if (TIMING && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && p.dbg_buf) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) p.dbg_buf[k] = tph[k] / (unsigned)(nb1 - nb0 > 0 ? nb1 - nb0 : 1);
+    p.dbg_buf[7] = nb1 - nb0;
+  }
   // ---- write this workgroup's slab: every parameter is owned by exactly one lane ----------------------
 #pragma unroll
   for (int l = 1; l < NH; ++l)

@@ -51,6 +51,7 @@ struct mile_sampler {
   LeNetGeom lg{};                       // MILE_MODEL_LENET geometry and parameter offsets
   // layer-wise GEMM path (MILE_GRAD_GEMM_F32): rocBLAS handle and activation workspace
   void *blas = nullptr;
+  long long *dbg_buf = nullptr;         // dev instrumentation (MILE_DEBUG=16)
   float *gemm_ws = nullptr, *gemm_ones = nullptr;
   int gemm_ones_n = 0;
   size_t gemm_ws_floats = 0;
@@ -292,6 +293,7 @@ int32_t mile_destroy(mile_sampler *s) {
   free_ws(s);
   if (s->gemm_ws) (void)hipFree(s->gemm_ws);
   if (s->gemm_ones) (void)hipFree(s->gemm_ones);
+  if (s->dbg_buf) (void)hipFree(s->dbg_buf);
   if (s->blas && g_rb.destroy) (void)g_rb.destroy(s->blas);
   for (auto ev : s->ev) (void)hipEventDestroy(ev);
   delete s;
@@ -473,6 +475,10 @@ static hipError_t launch_w128b(const GradParams &gp, int E, hipStream_t st) {
       attr_t = true;
     }
     k_grad_w128b<NH, 2, true><<<dim3(gp.S, E), 256, LY::BYTES, st>>>(gp);
+    long long hb[8];
+    if (gp.dbg_buf && hipMemcpy(hb, gp.dbg_buf, 64, hipMemcpyDeviceToHost) == hipSuccess)
+      fprintf(stderr, "w128b cycles per tile pair (%lld pairs): F1 %lld F2 %lld F3 %lld headbwd %lld L(1) %lld L(2) %lld first %lld\n", hb[7],
+              hb[0], hb[1], hb[2], hb[3], hb[4], hb[5], hb[6]);
     return hipGetLastError();
   }
   k_grad_w128b<NH, 2><<<dim3(gp.S, E), 256, LY::BYTES, st>>>(gp);
@@ -706,6 +712,9 @@ static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t s
   gp.slabs = s->slabs; gp.llpart = s->llpart;
   gp.N = s->N; gp.Npad = s->Npad; gp.Npb = s->Npb; gp.Fp = s->Fp; gp.S = S; gp.R = generic_R(s->ds); gp.dp = (s->ds.d + 3) / 4 * 4;
   { const char *dv = getenv("MILE_DEBUG"); gp.dbg = dv ? atoi(dv) : 0; }
+  gp.dbg_buf = nullptr;
+  if ((gp.dbg & 16) && !s->dbg_buf) HIP_TRY(hipMalloc(&s->dbg_buf, 64));
+  gp.dbg_buf = s->dbg_buf;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (s->timing) {
     if (s->ev_used + 2 > s->ev.size()) {
