@@ -491,3 +491,69 @@ def test_full_size_properties_b2(oracle):
     # energy_change = kinetic_change - l_new + l_old, consistently
     l_prev = torch.cat([s0.logdensity[None], info.logdensity[:-1]])
     assert (info.energy_change - (info.kinetic_change - info.logdensity + l_prev)).abs().max().item() < 5e-2
+
+
+def test_full_size_properties_b3(oracle):
+    """Size-independent properties at BASELINE's full B3 size (N=36000, E=512, d=34562) for the bf16-operand
+    kernel: agreement with the fp32 layer-wise path, additivity over data, permutation equivariance over
+    particles (bit-exact), determinism and unit momentum through steps."""
+    ospec, N, E = oracle.config_spec('B3')
+    prob = oracle.synthetic_problem(ospec, N, E, seed=0)
+    th = torch.from_numpy(prob['theta0'])
+    bf = _engine(ospec, prob['X'], prob['y'], 'mfma_w128_bf16')
+    lp1, g1 = bf.logpost_grad(th)
+    # against the fp32 layer-wise path (itself checked against the oracle at small sizes) on a slice of the particles
+    ge = _engine(ospec, prob['X'], prob['y'], 'gemm_f32')
+    lp2, g2 = ge.logpost_grad(th[:32])
+    assert _rel(lp1[:32].cpu(), lp2.cpu()) < 5e-3
+    rel = ((g1[:32] - g2).norm(dim=1) / g2.norm(dim=1)).max().item()
+    assert rel < 5e-2, rel
+    # a few particles against the oracle's bf16 recipe (fp64)
+    lo, go = oracle.logpost_and_grad_bf16(ospec, prob['theta0'][:2].astype(np.float64), prob['X'], prob['y'])
+    assert _rel(lp1[:2].cpu(), lo) < 1e-4
+    assert ((g1[:2].cpu().double() - torch.from_numpy(go)).norm(dim=1) / torch.from_numpy(go).norm(dim=1)).max().item() < 5e-3
+    # additivity over data (rows are rounded to bf16 one by one, so halves add up to fp32 summation order)
+    h = 17984                                               # a multiple of 64: both halves keep their row tiles
+    a = _engine(ospec, prob['X'][:h], prob['y'][:h], 'mfma_w128_bf16').logpost_grad(th)
+    b = _engine(ospec, prob['X'][h:], prob['y'][h:], 'mfma_w128_bf16').logpost_grad(th)
+    prior_g = -th.cuda()
+    assert _rel((a[1] + b[1] - prior_g).cpu(), g1.cpu()) < 2e-5
+    # particles are independent: a permutation of the rows of theta permutes the outputs bit for bit
+    perm = torch.randperm(E, generator=torch.Generator().manual_seed(1))
+    lp3, g3 = bf.logpost_grad(th[perm])
+    assert torch.equal(lp3.cpu(), lp1.cpu()[perm]) and torch.equal(g3.cpu(), g1.cpu()[perm])
+    # steps
+    ids = torch.arange(E, dtype=torch.int32)
+    eps = torch.full((E,), 1e-3)
+    L = torch.full((E,), 1.0)
+    s0 = bf.init(th, seed=5, particle_ids=ids)
+    s1, info, kept = bf.step(s0, eps, L, n_steps=4, seed=5, n_thinning=2, particle_ids=ids)
+    s1b, info_b, _ = bf.step(s0, eps, L, n_steps=4, seed=5, n_thinning=2, particle_ids=ids)
+    assert torch.equal(s1.position, s1b.position) and torch.equal(info.energy_change, info_b.energy_change)
+    assert (s1.momentum.double().norm(dim=1) - 1).abs().max().item() < 1e-5
+    assert kept.shape == (2, E, ospec.n_params) and torch.isfinite(kept).all() and torch.isfinite(info.energy_change).all()
+
+
+def test_full_size_properties_b4(oracle):
+    """BASELINE's B4 size (covertype-shaped: N=232404, F=54, [256 x 4, 7] softmax, 128 particles per GPU) on the
+    layer-wise fp32 path, which walks the rows in ~44 chunks here: additivity over data, permutation equivariance
+    over particles, generic-kernel agreement on a slice of rows and particles."""
+    ospec, N, E = oracle.config_spec('B4')
+    prob = oracle.synthetic_problem(ospec, N, E, seed=0)
+    th = torch.from_numpy(prob['theta0'])
+    ge = _engine(ospec, prob['X'], prob['y'])
+    assert ge.grad_kernel == 'gemm_f32'
+    lp1, g1 = ge.logpost_grad(th)
+    assert torch.isfinite(lp1).all() and torch.isfinite(g1).all()
+    h = 100000
+    a = _engine(ospec, prob['X'][:h], prob['y'][:h]).logpost_grad(th)
+    b = _engine(ospec, prob['X'][h:], prob['y'][h:]).logpost_grad(th)
+    assert _rel((a[1] + b[1] + th.cuda()).cpu(), g1.cpu()) < 5e-5          # prior gradient -theta counted once
+    perm = torch.randperm(E, generator=torch.Generator().manual_seed(2))
+    lp3, g3 = ge.logpost_grad(th[perm])
+    assert _rel(lp3.cpu(), lp1.cpu()[perm]) < 1e-6 and _rel(g3.cpu(), g1.cpu()[perm]) < 1e-6
+    # the single-launch generic kernel on 3 particles and the first 3000 rows
+    sub = slice(0, 3000)
+    r1 = _engine(ospec, prob['X'][sub], prob['y'][sub], 'gemm_f32').logpost_grad(th[:3])
+    r2 = _engine(ospec, prob['X'][sub], prob['y'][sub], 'generic').logpost_grad(th[:3])
+    assert _rel(r1[0].cpu(), r2[0].cpu()) < 2e-6 and _rel(r1[1].cpu(), r2[1].cpu()) < 2e-5
