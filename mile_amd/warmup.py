@@ -62,8 +62,18 @@ def predictor_update(energy_change, step_size, time, x_average, step_size_max, *
 
 def handle_nans(prev: IntegratorState, nxt: IntegratorState, step_size, step_size_max, energy_change):
     """warmup.py:468-483 per chain: reject a step whose position is non-finite and cap the
-    step size at 0.8 x the offending one."""
-    ok = torch.isfinite(nxt.position).all(dim=1)
+    step size at 0.8 x the offending one.
+
+    Almost every step is finite everywhere, and then the reference's where/nan_to_num select exactly ``nxt``:
+    that case is detected with one max-|.| reduction per tensor (NaN and inf both propagate through it) and
+    returns ``nxt`` without the seven [E, d] passes of the general path -- they cost more than the update
+    kernels of a step on the wide nets that take this host-driven loop."""
+    inf = float('inf')
+    ok = torch.isfinite(torch.linalg.vector_norm(nxt.position, ord=inf, dim=1))
+    rest = torch.stack([torch.linalg.vector_norm(nxt.momentum, ord=inf), torch.linalg.vector_norm(nxt.logdensity_grad, ord=inf),
+                        torch.linalg.vector_norm(nxt.logdensity, ord=inf)])
+    if bool(ok.all() & torch.isfinite(rest).all()):
+        return ok, nxt, torch.nan_to_num(step_size_max), torch.nan_to_num(energy_change)
     okc = ok[:, None]
     state = IntegratorState(
         torch.where(okc, torch.nan_to_num(nxt.position), prev.position),
@@ -186,10 +196,17 @@ def mclmc_find_L_and_step_size(eng, state: IntegratorState, rng_key, *, tune1_st
             trace.append(sub)
             done += c
         flat = torch.cat(trace, dim=0).permute(1, 0, 2).contiguous()       # [E, S, P]
+        # one ESS per chain and parameter.  With a single chain per call every (chain, parameter) column is
+        # independent, so groups of chains go through the estimator as extra columns (bounded workspace)
+        # instead of E python-level calls.
         mean_ratio = torch.empty(E, **f32)
-        for e in range(E):
-            ess = effective_sample_size(flat[e][None])
-            mean_ratio[e] = (tune3_steps / ess).mean()
+        S_, P_ = flat.shape[1], flat.shape[2]
+        group = max(1, min(E, (1 << 26) // max(S_ * P_, 1)))
+        for e0 in range(0, E, group):
+            blk = flat[e0:e0 + group]                                        # [G, S, P]
+            G = blk.shape[0]
+            ess = effective_sample_size(blk.permute(1, 0, 2).reshape(1, S_, G * P_)).reshape(G, P_)
+            mean_ratio[e0:e0 + G] = (tune3_steps / ess).mean(dim=1)
         L = Lfactor * eps * mean_ratio
     return state, MCLMCAdaptationState(L, eps, sqrt_diag_cov)
 
