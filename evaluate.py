@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""LPPD of a finished experiment (the consumer of mile_pointwise_loglik; mirrors what the reference's
+report notebook does with src/inference/evaluation.py:409-544 + src/inference/metrics.py:247-312 for the
+log-score part):
+
+    python evaluate.py -e results/mile_amd/<experiment> [--split test]
+
+Reloads config.yaml and the samples/<chain>/sample_<n>.npz files, rebuilds the data split with the same
+seed, evaluates all C x S samples on the split in one device pass and writes metrics.json next to them.
+"""
+import argparse
+import json
+from pathlib import Path
+
+import numpy as np
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser(description='LPPD / NLL of the samples of an experiment directory')
+    ap.add_argument('--exp', '-e', required=True, help='experiment directory (holds config.yaml and samples/)')
+    ap.add_argument('--split', default='test', choices=['train', 'valid', 'test'])
+    ap.add_argument('--device', default='cuda:0')
+    args = ap.parse_args()
+    exp = Path(args.exp)
+    from mile_amd.callbacks import load_samples_from_dir
+    from mile_amd.config import Config
+    from mile_amd.metrics import lppd, running_lppd
+    from mile_amd.trainer import BDETrainer
+    cfg = Config.from_file(exp / 'config.yaml').replace(logging=False)
+    tr = BDETrainer.__new__(BDETrainer)            # data + model spec only: no new experiment directory
+    tr.build_model(cfg)
+    spec = tr.prob_model.spec
+    samples = load_samples_from_dir(exp / cfg.training.sampler._dir_name, spec)       # [C, S, d]
+    x = getattr(tr.loader, f'{args.split}_x')
+    y = getattr(tr.loader, f'{args.split}_y')
+    x = np.ascontiguousarray(x).reshape(len(x), -1)
+    eng = tr.prob_model.engine(torch.from_numpy(np.ascontiguousarray(tr.loader.train_x).reshape(len(tr.loader.train_x), -1)),
+                               torch.from_numpy(np.ascontiguousarray(tr.loader.train_y)), device=args.device)
+    pw = eng.pointwise_loglik(torch.from_numpy(samples), torch.from_numpy(x), torch.from_numpy(np.ascontiguousarray(y)))
+    out = {'experiment': cfg.experiment_name, 'split': args.split, 'n_chains': int(samples.shape[0]),
+           'n_samples': int(samples.shape[1]), 'n_points': int(x.shape[0]),
+           'lppd': float(lppd(pw).item()), 'nll_mean': float(-pw.mean().item()),
+           'running_lppd_last': float(running_lppd(pw)[-1].item()),
+           'nonfinite_samples': int((~torch.isfinite(torch.from_numpy(samples)).all(dim=-1)).sum().item())}
+    (exp / 'metrics.json').write_text(json.dumps(out, indent=1) + '\n')
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

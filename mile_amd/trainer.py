@@ -56,6 +56,14 @@ class BDETrainer:
         # reproduces the reference's sequential chain groups when set
         self.n_devices = chains_per_group or self.n_chains
         self.train_plan = train_plan(self.n_chains, self.n_devices)
+        self.build_model(config)
+        self.exp_dir = self.config.experiment_dir
+        if self.rank == 0:
+            save_tree(self.exp_dir, self.prob_model.spec)
+        logger.info(f'> Trainer has been successfully initialized\n{self.prob_model}')
+
+    def build_model(self, config: Config):
+        """Data loader, model spec and probabilistic model of a config (also used by evaluate.py)."""
         task = 'regr' if config.data.task == 'regr' else 'classification'
         if config.model.model == 'LeNet':
             if config.data.data_type != 'image':
@@ -74,10 +82,6 @@ class BDETrainer:
         self.prob_model = ProbabilisticModel(module=self.spec_model, prior=config.training.sampler.prior,
                                              task=config.data.task, n_batches=1,
                                              grad_kernel=config.training.sampler.grad_kernel)
-        self.exp_dir = self.config.experiment_dir
-        if self.rank == 0:
-            save_tree(self.exp_dir, self.prob_model.spec)
-        logger.info(f'> Trainer has been successfully initialized\n{self.prob_model}')
 
     @property
     def key(self) -> PRNGKey:

@@ -300,6 +300,14 @@ def test_train_cli_runs_the_yaml_surface(tmp_path):
     assert sorted(p.name for p in (exp / 'samples' / '2').iterdir()) == ['sample_0.npz', 'sample_10.npz', 'sample_20.npz']
     log = (exp / 'training.log').read_text()
     assert 'time.sampling took' in log and 'Starting mclmc Sampling' in log
+    # evaluate.py: LPPD of the saved samples on the held-out split, through mile_pointwise_loglik
+    r = subprocess.run([sys.executable, str(ROOT / 'evaluate.py'), '-e', str(exp)], capture_output=True, text=True, cwd=ROOT,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    import json
+    m = json.loads((exp / 'metrics.json').read_text())
+    assert (m['n_chains'], m['n_samples'], m['split']) == (4, 3, 'test') and m['nonfinite_samples'] == 0
+    assert np.isfinite(m['lppd']) and np.isfinite(m['nll_mean']) and m['lppd'] >= -m['nll_mean'] - 1e-6   # Jensen
 
 
 def test_train_cli_classification_wide_net(tmp_path):

@@ -117,3 +117,9 @@ def test_train_cli_lenet_yaml(tmp_path):
     assert z['core.conv1.kernel'].shape == (5, 5, 3, 6) and z['core.conv2.kernel'].shape == (5, 5, 6, 16)
     assert z['core.fc1.kernel'].shape == (2 * 2 * 16, 120) and z['core.fc3.bias'].shape == (10,)
     assert all(np.isfinite(z[k]).all() for k in z.files)
+    r = subprocess.run([sys.executable, str(root / 'evaluate.py'), '-e', str(exp), '--split', 'valid'], capture_output=True,
+                       text=True, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    import json
+    m = json.loads((exp / 'metrics.json').read_text())
+    assert m['split'] == 'valid' and m['n_points'] == 30 and np.isfinite(m['lppd'])
