@@ -196,7 +196,8 @@ int32_t mile_step(mile_sampler *s, mile_state *state, const mile_step_args *args
 
 /* Replaces: the lax.scan over `step` in make_L_step_size_adaptation.run_steps
  * (src/training/warmup.py:352-363), i.e. phases 1+2 of mclmc_find_L_and_step_size, on the device.
- * Advances `state` in place; supported for d <= 16384 (returns MILE_ERR_INVALID beyond). */
+ * Advances `state` in place.  d <= 16384: the tuner runs inside the record-point update kernel; beyond that each
+ * step is an ordinary kernel step followed by one tuner launch (k_tune_post), same arithmetic. */
 int32_t mile_tune(mile_sampler *s, mile_state *state, const mile_tune_args *args, void *stream);
 
 /* Replaces: the per-sample forward pass + log_prob of the evaluation path, i.e. predict_from_samples /

@@ -52,6 +52,7 @@ struct mile_sampler {
   // layer-wise GEMM path (MILE_GRAD_GEMM_F32): rocBLAS handle and activation workspace
   void *blas = nullptr;
   long long *dbg_buf = nullptr;         // dev instrumentation (MILE_DEBUG=16)
+  float *tune_info = nullptr;           // [E_cap, 3] scratch MCLMCInfo of mile_tune's large-d path
   float *gemm_ws = nullptr, *gemm_ones = nullptr;
   int gemm_ones_n = 0;
   size_t gemm_ws_floats = 0;
@@ -280,6 +281,8 @@ static void free_ws(mile_sampler *s) {
   if (s->alt_g) (void)hipFree(s->alt_g);
   if (s->alt_logp) (void)hipFree(s->alt_logp);
   s->alt_x = s->alt_u = s->alt_g = s->alt_logp = nullptr;
+  if (s->tune_info) (void)hipFree(s->tune_info);
+  s->tune_info = nullptr;
   s->slabs = s->llpart = s->dK = s->lold = nullptr;
   s->E_cap = s->S_cap = 0;
 }
@@ -294,6 +297,7 @@ int32_t mile_destroy(mile_sampler *s) {
   if (s->gemm_ws) (void)hipFree(s->gemm_ws);
   if (s->gemm_ones) (void)hipFree(s->gemm_ones);
   if (s->dbg_buf) (void)hipFree(s->dbg_buf);
+  if (s->tune_info) (void)hipFree(s->tune_info);
   if (s->blas && g_rb.destroy) (void)g_rb.destroy(s->blas);
   for (auto ev : s->ev) (void)hipEventDestroy(ev);
   delete s;
@@ -1053,8 +1057,8 @@ int32_t mile_tune(mile_sampler *s, mile_state *state, const mile_tune_args *a, v
     return fail(MILE_ERR_INVALID, "mile_tune: unknown refresh mode");
   const int E = state->n_particles, d = s->ds.d;
   if (E < 1) return fail(MILE_ERR_INVALID, "mile_tune: n_particles must be >= 1");
-  if ((d >> 2) < 1 || (d >> 2) > UPD_NT * UPD_QMAX)
-    return fail(MILE_ERR_INVALID, "mile_tune: the on-device tuner supports 4 <= d <= 16384");
+  if ((d >> 2) < 1) return fail(MILE_ERR_INVALID, "mile_tune: d < 4");
+  const bool big = (d >> 2) > UPD_NT * UPD_QMAX || getenv("MILE_TUNE_POST") != nullptr;   // beyond k_update_fast's register cache
   if (a->n_steps == 0) return MILE_OK;
   hipStream_t st = (hipStream_t)stream;
   HIP_TRY(hipSetDevice(s->device));
@@ -1077,6 +1081,69 @@ int32_t mile_tune(mile_sampler *s, mile_state *state, const mile_tune_args *a, v
   const size_t Ed = (size_t)E * d;
   auto noise_at = [&](int i, int k) -> const float * { return a->noise ? a->noise + ((size_t)i * 2 + k) * Ed : nullptr; };
   auto set_state = [](UpdParams &u, const Buf &b) { u.x = b.x; u.u = b.u; u.g = b.g; u.logp = b.logp; };
+  auto target_var = [&](int sp) -> float {
+    const double tot = (double)a->schedule_total, vs = a->desired_energy_var_start, ve = a->desired_energy_var_end;
+    if (vs > 2.0) {
+      const double tau = tot / 4.0, ex = std::exp(-(double)sp / tau);
+      return (float)(vs * ex + ve * (1.0 - ex));
+    }
+    return (float)(vs - (vs - ve) * std::min((double)sp / tot, 1.0));
+  };
+
+  if (big) {
+    // Large d: an ordinary in-place kernel step (two-pass update kernels), the previous state copied aside first,
+    // then k_tune_post applies the predictor, the rejection of non-finite steps and the streaming averages.
+    if (!s->tune_info) HIP_TRY(hipMalloc(&s->tune_info, (size_t)s->E_cap * 3 * 4));
+    for (int i = 0; i < a->n_steps; ++i) {
+      const int64_t gstep = a->step_offset + i;
+      HIP_TRY(hipMemcpyAsync(B.x, A.x, Ed * 4, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipMemcpyAsync(B.u, A.u, Ed * 4, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipMemcpyAsync(B.g, A.g, Ed * 4, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipMemcpyAsync(B.logp, A.logp, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
+      float *info_i = a->out_info ? a->out_info + (size_t)i * E * 3 : s->tune_info;
+      {
+        UpdParams u = up;
+        set_state(u, A);
+        u.flags = UPD_START | UPD_B2 | UPD_A | (oso ? UPD_OB : 0);
+        u.zB = noise_at(i, 0); u.stepB = (uint32_t)gstep; u.stageB = 0; u.hB = 0.5f;
+        u.coef_b2 = b1; u.coef_a = 0.5f;
+        launch_update(u, E, st);
+      }
+      int rc = launch_grad(s, A.x, E, st);
+      if (rc) return rc;
+      {
+        UpdParams u = up;
+        set_state(u, A);
+        u.flags = UPD_FROM_SLABS | UPD_B1 | UPD_A | UPD_NO_G;
+        u.coef_b1 = b2; u.coef_a = 0.5f;
+        launch_update(u, E, st);
+      }
+      rc = launch_grad(s, A.x, E, st);
+      if (rc) return rc;
+      {
+        UpdParams u = up;
+        set_state(u, A);
+        u.flags = UPD_FROM_SLABS | UPD_B1 | UPD_OA | UPD_RECORD;
+        u.coef_b1 = b1;
+        u.zA = noise_at(i, 1); u.stepA = (uint32_t)gstep; u.stageA = 1; u.hA = oso ? 0.5f : 1.0f;
+        u.out_info = info_i;
+        launch_update(u, E, st);
+      }
+      TunePostParams tp{};
+      tp.d = d; tp.x = A.x; tp.u = A.u; tp.g = A.g; tp.logp = A.logp;
+      tp.bk_x = B.x; tp.bk_u = B.u; tp.bk_g = B.g; tp.bk_logp = B.logp;
+      tp.info = info_i;
+      tp.t_eps = a->step_size; tp.t_eps_max = a->step_size_max; tp.t_time = a->time; tp.t_xavg = a->x_average;
+      tp.t_W = a->stream_weight; tp.t_avg = a->stream_average;
+      const int sp = a->schedule_step0 + i;
+      tp.t_mask = sp < a->n_mask_steps ? 1.0f : 0.0f;
+      tp.t_var = target_var(sp);
+      tp.t_trust = a->trust_in_estimate; tp.t_decay = a->decay_rate;
+      k_tune_post<<<E, AUX_NT, 0, st>>>(tp);
+    }
+    HIP_TRY(hipGetLastError());
+    return MILE_OK;
+  }
 
   for (int i = 0; i < a->n_steps; ++i) {
     const Buf &cur = (i & 1) ? B : A, &nxt = (i & 1) ? A : B;
@@ -1112,13 +1179,7 @@ int32_t mile_tune(mile_sampler *s, mile_state *state, const mile_tune_args *a, v
       u.t_W = a->stream_weight; u.t_avg = a->stream_average;
       const int sp = a->schedule_step0 + i;
       u.t_mask = sp < a->n_mask_steps ? 1.0f : 0.0f;
-      const double tot = (double)a->schedule_total, vs = a->desired_energy_var_start, ve = a->desired_energy_var_end;
-      if (vs > 2.0) {
-        const double tau = tot / 4.0, ex = std::exp(-(double)sp / tau);
-        u.t_var = (float)(vs * ex + ve * (1.0 - ex));
-      } else {
-        u.t_var = (float)(vs - (vs - ve) * std::min((double)sp / tot, 1.0));
-      }
+      u.t_var = target_var(sp);
       u.t_trust = a->trust_in_estimate; u.t_decay = a->decay_rate;
       if (a->out_info) u.out_info = a->out_info + (size_t)i * E * 3;
       launch_update(u, E, st);

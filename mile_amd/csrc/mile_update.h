@@ -670,3 +670,69 @@ __global__ __launch_bounds__(AUX_NT) void k_debug_noise(int d, uint64_t seed, co
       if (4 * q + m < d) out[(size_t)e * d + 4 * q + m] = zz[m];
   }
 }
+
+// Warm-up tuner as a separate launch after a kernel step, for d beyond k_update_fast's register cache
+// (same arithmetic as the UPD_TUNE block above: predictor + handle_nans warmup.py:271-326,468-483, streaming
+// averages :343-348).  x/u/g/logp: the state after the step, bk_*: the state before it, info: the step's
+// MCLMCInfo triple [E, 3].  One workgroup per particle.
+struct TunePostParams {
+  int32_t d;
+  float *x, *u, *g, *logp;
+  const float *bk_x, *bk_u, *bk_g, *bk_logp;
+  float *info;
+  float *t_eps, *t_eps_max, *t_time, *t_xavg, *t_W, *t_avg;
+  float t_mask, t_var, t_trust, t_decay;
+};
+
+__global__ __launch_bounds__(AUX_NT) void k_tune_post(const TunePostParams p) {
+  __shared__ float red[AUX_NT / 64];
+  __shared__ float bc[4];
+  const int tid = threadIdx.x, e = blockIdx.x, d = p.d;
+  const size_t base = (size_t)e * d;
+  float bad = 0.0f;
+  for (int i = tid; i < d; i += AUX_NT) bad += isfinite(p.x[base + i]) ? 0.0f : 1.0f;
+  bad = wave_sum(bad);
+  if ((tid & 63) == 0) red[tid >> 6] = bad;
+  __syncthreads();
+  if (tid == 0) {
+    constexpr float FMAX = 3.4028234663852886e38f;
+    float cnt = 0.0f;
+    for (int w = 0; w < AUX_NT / 64; ++w) cnt += red[w];
+    const bool ok = cnt == 0.0f;
+    const float eps = p.t_eps[e];
+    float dE = p.info[3 * e + 2];
+    dE = ok ? (isnan(dE) ? 0.0f : fminf(fmaxf(dE, -FMAX), FMAX)) : 0.0f;
+    const float emax = ok ? fminf(p.t_eps_max[e], FMAX) : 0.8f * eps;
+    const float xi = dE * dE / ((float)d * p.t_var) + 1e-8f;
+    const float lx = logf(xi) / (6.0f * p.t_trust);
+    const float w = expf(-0.5f * lx * lx);
+    const float e2 = eps * eps;
+    const float xavg = p.t_decay * p.t_xavg[e] + w * (xi / (e2 * e2 * e2));
+    const float tm = p.t_decay * p.t_time[e] + w;
+    float en = powf(xavg / tm, -1.0f / 6.0f);
+    en = (en < emax ? 1.0f : 0.0f) * en + (en > emax ? 1.0f : 0.0f) * emax;
+    const float Wold = p.t_W[e], wgt = (1.0f - p.t_mask) * (ok ? 1.0f : 0.0f) * en;
+    p.t_eps[e] = en; p.t_eps_max[e] = emax; p.t_xavg[e] = xavg; p.t_time[e] = tm; p.t_W[e] = Wold + wgt;
+    if (!ok) { p.logp[e] = p.bk_logp[e]; p.info[3 * e] = p.bk_logp[e]; }
+    bc[0] = ok ? 1.0f : 0.0f; bc[1] = Wold; bc[2] = wgt;
+  }
+  __syncthreads();
+  const bool ok = bc[0] != 0.0f;
+  if (!ok) {   // handle_nans: the chain keeps its previous state
+    for (int i = tid; i < d; i += AUX_NT) {
+      p.x[base + i] = p.bk_x[base + i];
+      p.u[base + i] = p.bk_u[base + i];
+      p.g[base + i] = p.bk_g[base + i];
+    }
+    return;
+  }
+  if (p.t_mask == 0.0f) {   // streaming_average_update of [x, x^2] with weight eps (zero_prevention = 0)
+    const float Wold = bc[1], wgt = bc[2], den = 1.0f / (Wold + wgt);
+    float *a0 = p.t_avg + (size_t)e * 2 * d, *a1 = a0 + d;
+    for (int i = tid; i < d; i += AUX_NT) {
+      const float xv = p.x[base + i];
+      a0[i] = (Wold * a0[i] + wgt * xv) * den;
+      a1[i] = (Wold * a1[i] + wgt * xv * xv) * den;
+    }
+  }
+}

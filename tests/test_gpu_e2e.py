@@ -218,10 +218,45 @@ def test_device_tuner_matches_host_loop(oracle):
     assert _rel(outp[False][1].step_size.cpu(), outp[True][1].step_size.cpu()) < 5e-2
 
 
-def test_device_tuner_rejects_nonfinite_steps(oracle):
+@pytest.mark.parametrize('F,hs,force_post', [(5, (64, 64, 64, 2), True), (9, (128, 128, 2), False)])
+def test_device_tuner_post_kernel_matches_host_loop(oracle, monkeypatch, F, hs, force_post):
+    """mile_tune's second form -- an ordinary kernel step plus k_tune_post -- which every net with d > 16384 takes
+    (and a small one here through the MILE_TUNE_POST test hook), against the host-driven loop with the same noise."""
+    from mile_amd.warmup import mclmc_find_L_and_step_size
+    if force_post:
+        monkeypatch.setenv('MILE_TUNE_POST', '1')
+    ospec = oracle.ModelSpec(F, hs)
+    E, d = 3, ospec.n_params
+    assert force_post or d > 16384
+    prob = oracle.synthetic_problem(ospec, 90, E, seed=6)
+    rng = np.random.default_rng(8)
+    t1, t2 = 7, 4
+    z0 = torch.from_numpy(rng.standard_normal((E, d)).astype(np.float32))
+    n12 = torch.from_numpy(rng.standard_normal((t1 + t2, 2, E, d)).astype(np.float32)).cuda()
+    eng = _engine(ospec, prob['X'], prob['y'])
+    assert eng.supports_device_tuner
+    kw = dict(tune1_steps=t1, tune2_steps=t2, tune3_steps=0, step_size_init=0.002, desired_energy_var_start=0.5,
+              desired_energy_var_end=0.1, trust_in_estimate=1.5, num_effective_samples=100,
+              diagonal_preconditioning=False, noise_fn=lambda i: n12[i])
+    out = {}
+    for host in (True, False):
+        s0 = eng.init(torch.from_numpy(prob['theta0']), noise=z0)
+        out[host] = mclmc_find_L_and_step_size(eng, s0, 0, force_host_loop=host, **kw)
+    (sh, ph), (sd, pd) = out[True], out[False]
+    assert _rel(pd.step_size.cpu(), ph.step_size.cpu()) < 2e-3
+    assert _rel(pd.L.cpu(), ph.L.cpu()) < 2e-3
+    assert _rel(sd.position.cpu(), sh.position.cpu()) < 1e-3
+    assert _rel(sd.logdensity.cpu(), sh.logdensity.cpu()) < 1e-4
+
+
+@pytest.mark.parametrize('post', [False, True])
+def test_device_tuner_rejects_nonfinite_steps(oracle, monkeypatch, post):
     """handle_nans on the device: a chain whose step leaves the finite numbers keeps its state and gets
-    step_size_max = 0.8 eps; the other chains follow the predictor formula."""
+    step_size_max = 0.8 eps; the other chains follow the predictor formula.  Both forms of mile_tune: the tuner
+    fused into the record-point kernel, and the separate k_tune_post launch large nets take."""
     from mile_amd.warmup import predictor_update
+    if post:
+        monkeypatch.setenv('MILE_TUNE_POST', '1')
     ospec = oracle.ModelSpec(5, (16, 16, 2))
     E, d = 3, ospec.n_params
     prob = oracle.synthetic_problem(ospec, 80, E, seed=6)
