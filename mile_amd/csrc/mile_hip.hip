@@ -510,13 +510,28 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
   if (g_rb.set_stream(s->blas, st) != 0) return fail(MILE_ERR_HIP, "rocblas_set_stream failed");
   const size_t HW = (size_t)g.H * g.W, P1 = (size_t)g.hp1 * g.wp1, HW2 = (size_t)g.h2 * g.w2;
   const size_t n_a1 = 6 * HW, n_p1 = 6 * P1, n_col2 = 150 * HW2, n_a2 = 16 * HW2, n_p2 = g.flat;
-  size_t per = n_a1 + n_p1 + n_col2 + n_a2 + n_p2 + 120 + 84 + g.K;
+  // direct convolution kernels (LDS tiles per image) unless the image is too large for them or the im2col + SGEMM
+  // form is asked for (MILE_LENET_GEMM=1: kept as the second implementation / fallback)
+  const int ipw = 8;                                                  // images per workgroup
+  const size_t lds_f1 = (size_t)(25 * g.C * 8 + 8 + g.C * (g.H + 4) * (g.W + 4)) * 4;
+  const int KT1 = 25 * g.C;
+  const unsigned nt1 = (unsigned)std::min(512, (std::max(1, 256 / KT1) * KT1 + 63) / 64 * 64), nt2 = 320;   // k_conv5_dw block sizes
+  const size_t G1 = nt1 / KT1, G2 = nt2 / 150;                       // pixel groups; their partial sums alias the tiles at the end
+  const size_t lds_w1 = std::max((size_t)(g.C * (g.H + 4) * (g.W + 4)) + HW * 6, (G1 - 1) * (size_t)(KT1 * 6 + 6)) * 4;
+  const size_t lds_f2 = (size_t)(150 * 16 + 16 + 6 * P1) * 4, lds_x2 = (size_t)(2400 + (g.h2 + 8) * (g.w2 + 8) * 16) * 4;
+  const size_t lds_w2 = std::max(6 * P1 + HW2 * 16, (G2 - 1) * (size_t)(2400 + 16)) * 4;
+  const size_t lds_max = std::max({lds_f1, lds_w1, lds_f2, lds_x2, lds_w2});
+  const bool direct = getenv("MILE_LENET_GEMM") == nullptr && g.C <= 16 && lds_max <= 150 * 1024;
+  size_t per = n_a1 + n_p1 + (direct ? 0 : n_col2) + n_a2 + n_p2 + 120 + 84 + g.K;
   if (grad) per += 84 + 120 + n_p2 + n_a2 + n_p1 + n_a1;
-  const size_t shared = 25 * (size_t)g.C * HW;
+  const size_t shared = direct ? 0 : 25 * (size_t)g.C * HW;
   size_t R = ((size_t)1 << 30) / ((size_t)E * per + shared);
   R = std::max<size_t>(1, std::min<size_t>(R, (size_t)N));
   if (const char *rv = getenv("MILE_GEMM_ROWS")) R = std::max<size_t>(1, std::min<size_t>((size_t)atoll(rv), (size_t)N));
-  const size_t need = R * ((size_t)E * per + shared);
+  const size_t nwg_max = (R + ipw - 1) / ipw;
+  const size_t n_part1 = direct && grad ? (size_t)E * nwg_max * (25 * g.C * 6 + 6) : 0;
+  const size_t n_part2 = direct && grad ? (size_t)E * nwg_max * (2400 + 16) : 0;
+  const size_t need = R * ((size_t)E * per + shared) + n_part1 + n_part2;
   if (need > s->gemm_ws_floats) {
     if (s->gemm_ws) (void)hipFree(s->gemm_ws);
     s->gemm_ws = nullptr; s->gemm_ws_floats = 0;
@@ -535,10 +550,22 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
   const size_t ER = (size_t)E * R;
   float *q = s->gemm_ws;
   auto take = [&](size_t n) { float *r = q; q += n; return r; };
-  float *col1 = take(R * shared), *a1 = take(ER * n_a1), *p1 = take(ER * n_p1), *col2 = take(ER * n_col2), *a2 = take(ER * n_a2);
+  float *col1 = take(R * shared), *a1 = take(ER * n_a1), *p1 = take(ER * n_p1), *col2 = take(direct ? 0 : ER * n_col2), *a2 = take(ER * n_a2);
   float *p2 = take(ER * n_p2), *f1 = take(ER * 120), *f2 = take(ER * 84), *out = take(ER * g.K);
   float *df2 = nullptr, *df1 = nullptr, *dp2 = nullptr, *dz2 = nullptr, *dp1 = nullptr, *dz1 = nullptr;
   if (grad) { df2 = take(ER * 84); df1 = take(ER * 120); dp2 = take(ER * n_p2); dz2 = take(ER * n_a2); dp1 = take(ER * n_p1); dz1 = take(ER * n_a1); }
+  float *part1 = take(n_part1), *part2 = take(n_part2);
+  if (direct) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      HIP_TRY(hipFuncSetAttribute((const void *)k_conv5_fwd<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void *)k_conv5_fwd<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void *)k_conv5_dw<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void *)k_conv5_dw<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void *)k_conv5_dx<6, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      attr_done = true;
+    }
+  }
   const float one = 1.0f, zero = 0.0f;
   auto blocks = [](long long n) { return (unsigned)std::min<long long>((n + 255) / 256, 65535); };
   // row-major C[rows x fout] = A[rows x fin] W[fin x fout] per batch entry; W from theta (+ offset), batch stride d
@@ -553,14 +580,23 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
     const long long Rc = std::min<long long>((long long)R, N - r0), B = (long long)E * Rc;
     const long long M1 = Rc * (long long)HW, M2 = Rc * (long long)HW2;
     // ---- forward
-    k_im2col5<<<blocks(M1 * 25 * g.C), 256, 0, st>>>(X + (size_t)r0 * g.C * HW, col1, Rc, g.H, g.W, g.C, g.H, g.W, 2,
-                                                     (long long)g.C * HW, g.W, 1, (long long)HW);
-    if (fwd(g.k_c1, 25 * g.C, 6, col1, 0, M1, a1)) return fail(MILE_ERR_HIP, "rocblas sgemm (conv1) failed");
-    bias_act(a1, g.b_c1, 6, M1, 1);
-    k_avgpool2<<<blocks(B * (long long)n_p1), 256, 0, st>>>(a1, p1, B, g.H, g.W, 6);
-    k_im2col5<<<blocks(B * (long long)n_col2), 256, 0, st>>>(p1, col2, B, g.hp1, g.wp1, 6, g.h2, g.w2, 0, (long long)n_p1, g.wp1 * 6, 6, 1);
-    if (fwd(g.k_c2, 150, 16, col2, M2 * 150, M2, a2)) return fail(MILE_ERR_HIP, "rocblas sgemm (conv2) failed");
-    bias_act(a2, g.b_c2, 16, M2, 1);
+    const float *Xc = X + (size_t)r0 * g.C * HW;
+    const unsigned nwg = (unsigned)((Rc + ipw - 1) / ipw);
+    if (direct) {
+      k_conv5_fwd<6><<<dim3(nwg, E), 256, lds_f1, st>>>(Xc, 0, (long long)g.C * HW, g.W, 1, (long long)HW, g.C, g.H, g.W, 2, theta, g.k_c1,
+                                                       g.b_c1, d, a1, (int)Rc, ipw, act);
+      k_avgpool2<<<blocks(B * (long long)n_p1), 256, 0, st>>>(a1, p1, B, g.H, g.W, 6);
+      k_conv5_fwd<16><<<dim3(nwg, E), 256, lds_f2, st>>>(p1, Rc * (long long)n_p1, (long long)n_p1, g.wp1 * 6, 6, 1, 6, g.hp1, g.wp1, 0, theta,
+                                                        g.k_c2, g.b_c2, d, a2, (int)Rc, ipw, act);
+    } else {
+      k_im2col5<<<blocks(M1 * 25 * g.C), 256, 0, st>>>(Xc, col1, Rc, g.H, g.W, g.C, g.H, g.W, 2, (long long)g.C * HW, g.W, 1, (long long)HW);
+      if (fwd(g.k_c1, 25 * g.C, 6, col1, 0, M1, a1)) return fail(MILE_ERR_HIP, "rocblas sgemm (conv1) failed");
+      bias_act(a1, g.b_c1, 6, M1, 1);
+      k_avgpool2<<<blocks(B * (long long)n_p1), 256, 0, st>>>(a1, p1, B, g.H, g.W, 6);
+      k_im2col5<<<blocks(B * (long long)n_col2), 256, 0, st>>>(p1, col2, B, g.hp1, g.wp1, 6, g.h2, g.w2, 0, (long long)n_p1, g.wp1 * 6, 6, 1);
+      if (fwd(g.k_c2, 150, 16, col2, M2 * 150, M2, a2)) return fail(MILE_ERR_HIP, "rocblas sgemm (conv2) failed");
+      bias_act(a2, g.b_c2, 16, M2, 1);
+    }
     k_avgpool2<<<blocks(B * (long long)n_p2), 256, 0, st>>>(a2, p2, B, g.h2, g.w2, 16);
     if (fwd(g.k_f1, g.flat, 120, p2, Rc * g.flat, Rc, f1)) return fail(MILE_ERR_HIP, "rocblas sgemm (fc1) failed");
     bias_act(f1, g.b_f1, 120, Rc, 1);
@@ -600,11 +636,23 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
     if (dW(g.k_f1, g.b_f1, g.flat, 120, p2, Rc * g.flat, df1, Rc)) return fail(MILE_ERR_HIP, "rocblas sgemm (d fc1) failed");
     if (dX(g.k_f1, g.flat, 120, df1, Rc, dp2)) return fail(MILE_ERR_HIP, "rocblas sgemm (d fc1 in) failed");
     k_unpool_actgrad<<<blocks(B * (long long)n_a2), 256, 0, st>>>(dp2, a2, dz2, B, g.h2, g.w2, 16, act);
-    if (dW(g.k_c2, g.b_c2, 150, 16, col2, M2 * 150, dz2, M2)) return fail(MILE_ERR_HIP, "rocblas sgemm (d conv2) failed");
-    if (dX(g.k_c2, 150, 16, dz2, M2, col2)) return fail(MILE_ERR_HIP, "rocblas sgemm (d conv2 in) failed");   // d(col2) over col2
-    k_col2im5<<<blocks(B * (long long)n_p1), 256, 0, st>>>(col2, dp1, B, g.h2, g.w2, 6);
-    k_unpool_actgrad<<<blocks(B * (long long)n_a1), 256, 0, st>>>(dp1, a1, dz1, B, g.H, g.W, 6, act);
-    if (dW(g.k_c1, g.b_c1, 25 * g.C, 6, col1, 0, dz1, M1)) return fail(MILE_ERR_HIP, "rocblas sgemm (d conv1) failed");
+    if (direct) {
+      const int acc = chunk != 0;
+      k_conv5_dw<16><<<dim3(nwg, E), nt2, lds_w2, st>>>(p1, Rc * (long long)n_p1, (long long)n_p1, g.wp1 * 6, 6, 1, 6, g.hp1, g.wp1, 0, dz2,
+                                                       part2, (int)Rc, ipw);
+      k_conv_reduce<<<dim3(10, E), 256, 0, st>>>(part2, (int)nwg, 2400, 16, slab, dp, g.k_c2, g.b_c2, acc);
+      k_conv5_dx<6, 16><<<dim3(nwg, E), 256, lds_x2, st>>>(dz2, theta, g.k_c2, d, dp1, (int)Rc, g.h2, g.w2, ipw);
+      k_unpool_actgrad<<<blocks(B * (long long)n_a1), 256, 0, st>>>(dp1, a1, dz1, B, g.H, g.W, 6, act);
+      k_conv5_dw<6><<<dim3(nwg, E), nt1, lds_w1, st>>>(Xc, 0, (long long)g.C * HW, g.W, 1, (long long)HW, g.C, g.H, g.W, 2, dz1, part1, (int)Rc,
+                                                      ipw);
+      k_conv_reduce<<<dim3(2, E), 256, 0, st>>>(part1, (int)nwg, KT1 * 6, 6, slab, dp, g.k_c1, g.b_c1, acc);
+    } else {
+      if (dW(g.k_c2, g.b_c2, 150, 16, col2, M2 * 150, dz2, M2)) return fail(MILE_ERR_HIP, "rocblas sgemm (d conv2) failed");
+      if (dX(g.k_c2, 150, 16, dz2, M2, col2)) return fail(MILE_ERR_HIP, "rocblas sgemm (d conv2 in) failed");   // d(col2) over col2
+      k_col2im5<<<blocks(B * (long long)n_p1), 256, 0, st>>>(col2, dp1, B, g.h2, g.w2, 6);
+      k_unpool_actgrad<<<blocks(B * (long long)n_a1), 256, 0, st>>>(dp1, a1, dz1, B, g.H, g.W, 6, act);
+      if (dW(g.k_c1, g.b_c1, 25 * g.C, 6, col1, 0, dz1, M1)) return fail(MILE_ERR_HIP, "rocblas sgemm (d conv1) failed");
+    }
   }
   HIP_TRY(hipGetLastError());
   return MILE_OK;

@@ -81,3 +81,186 @@ __global__ __launch_bounds__(256) void k_col2im5(const float *dcol, float *dst, 
     dst[i] = s;
   }
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Direct 5x5 convolutions (second implementation of the conv half: no im2col matrices in HBM, no skinny
+// GEMMs).  One workgroup = one particle x a range of images; the particle's kernel sits in LDS, each image's
+// input (zero-padded) and, for the gradients, its dZ are staged in LDS tiles.  NHWC activations
+// [E][R][H][W][C]; the first layer's input is the shared NCHW image chunk (general strides, particle stride 0).
+// ------------------------------------------------------------------------------------------------------
+template <int COUT>
+struct ConvPad { static constexpr int P = (COUT + 3) / 4 * 4; };
+
+// out[e][b][y][x][co] = act(bias[co] + sum_{kh,kw,ci} in[b][y+kh-pad][x+kw-pad][ci] K[kh][kw][ci][co])
+template <int COUT>
+__global__ __launch_bounds__(256) void k_conv5_fwd(const float *in, long long sE, long long sB, long long sH, long long sW, long long sC,
+                                                   int CIN, int H, int W, int pad, const float *theta, int k_off, int b_off, int d, float *out,
+                                                   int R, int ipw, int activation) {
+  constexpr int CP = ConvPad<COUT>::P;
+  extern __shared__ __attribute__((aligned(16))) float cl[];
+  const int tid = threadIdx.x, e = blockIdx.y;
+  const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4, Hp = H + 2 * pad, Wp = W + 2 * pad;
+  float *Ksh = cl;                       // [25*CIN][CP]
+  float *bsh = Ksh + 25 * CIN * CP;      // [CP]
+  float *tile = bsh + CP;                // [CIN][Hp][Wp]
+  const float *K = theta + (size_t)e * d + k_off, *bias = theta + (size_t)e * d + b_off;
+  for (int i = tid; i < 25 * CIN * CP; i += 256) Ksh[i] = (i % CP) < COUT ? K[(i / CP) * COUT + (i % CP)] : 0.0f;
+  if (tid < CP) bsh[tid] = tid < COUT ? bias[tid] : 0.0f;
+  const int b0 = blockIdx.x * ipw, b1 = min(R, b0 + ipw);
+  for (int b = b0; b < b1; ++b) {
+    __syncthreads();
+    const float *src = in + (size_t)e * sE + (size_t)b * sB;
+    for (int i = tid; i < CIN * Hp * Wp; i += 256) {
+      const int xx = i % Wp, yy = (i / Wp) % Hp, ci = i / (Wp * Hp);
+      const int h = yy - pad, w = xx - pad;
+      tile[i] = (h >= 0 && h < H && w >= 0 && w < W) ? src[h * sH + w * sW + ci * sC] : 0.0f;
+    }
+    __syncthreads();
+    float *dst = out + ((size_t)e * R + b) * Ho * Wo * COUT;
+    for (int p = tid; p < Ho * Wo; p += 256) {
+      const int y = p / Wo, x = p % Wo;
+      float acc[CP];
+#pragma unroll
+      for (int c = 0; c < CP; ++c) acc[c] = bsh[c];
+      for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+        for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 5; ++kw) {
+            const float v = tile[(ci * Hp + y + kh) * Wp + x + kw];
+            const float *kr = Ksh + ((kh * 5 + kw) * CIN + ci) * CP;
+#pragma unroll
+            for (int c = 0; c < CP; ++c) acc[c] = fmaf(v, kr[c], acc[c]);
+          }
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) dst[(size_t)p * COUT + c] = act_fwd(activation, acc[c]);
+    }
+  }
+}
+
+// VALID 5x5 conv, gradient w.r.t. the input: din[e][b][yi][xi][ci] = sum_{kh,kw,co} dz[e][b][yi-kh][xi-kw][co] K[kh][kw][ci][co]
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void k_conv5_dx(const float *dz, const float *theta, int k_off, int d, float *din, int R, int Ho, int Wo,
+                                                  int ipw) {
+  extern __shared__ __attribute__((aligned(16))) float cl[];
+  const int tid = threadIdx.x, e = blockIdx.y;
+  const int H = Ho + 4, W = Wo + 4, Ht = Ho + 8, Wt = Wo + 8;
+  float *Ksh = cl;                         // [25*CIN][COUT]
+  float *tile = Ksh + 25 * CIN * COUT;     // [Ht][Wt][COUT], zero halo of 4
+  const float *K = theta + (size_t)e * d + k_off;
+  for (int i = tid; i < 25 * CIN * COUT; i += 256) Ksh[i] = K[i];
+  const int b0 = blockIdx.x * ipw, b1 = min(R, b0 + ipw);
+  for (int b = b0; b < b1; ++b) {
+    __syncthreads();
+    const float *src = dz + ((size_t)e * R + b) * Ho * Wo * COUT;
+    for (int i = tid; i < Ht * Wt * COUT; i += 256) {
+      const int c = i % COUT, xx = (i / COUT) % Wt, yy = i / (COUT * Wt);
+      const int y = yy - 4, x = xx - 4;
+      tile[i] = (y >= 0 && y < Ho && x >= 0 && x < Wo) ? src[((size_t)y * Wo + x) * COUT + c] : 0.0f;
+    }
+    __syncthreads();
+    float *dst = din + ((size_t)e * R + b) * H * W * CIN;
+    for (int p = tid; p < H * W; p += 256) {
+      const int yi = p / W, xi = p % W;
+      float acc[CIN];
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci) acc[ci] = 0.0f;
+#pragma unroll
+      for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 5; ++kw) {
+          const float *zv = tile + ((yi - kh + 4) * Wt + (xi - kw + 4)) * COUT;
+#pragma unroll
+          for (int ci = 0; ci < CIN; ++ci) {
+            const float *kr = Ksh + ((kh * 5 + kw) * CIN + ci) * COUT;
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) acc[ci] = fmaf(zv[c], kr[c], acc[ci]);
+          }
+        }
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci) dst[(size_t)p * CIN + ci] = acc[ci];
+    }
+  }
+}
+
+// Kernel / bias gradient of one image range: part[(e * nwg + wg) * (25*CIN*COUT + COUT) + ...]
+//   dK[kh][kw][ci][co] = sum_{b,y,x} in[b][y+kh-pad][x+kw-pad][ci] dz[b][y][x][co],  db[co] = sum dz
+// Thread (k, g): k = (kh, kw, ci) index, g = pixel group; COUT accumulators per thread; groups reduced through LDS.
+template <int COUT>
+__global__ __launch_bounds__(512) void k_conv5_dw(const float *in, long long sE, long long sB, long long sH, long long sW, long long sC, int CIN,
+                                                  int H, int W, int pad, const float *dz, float *part, int R, int ipw) {
+  extern __shared__ __attribute__((aligned(16))) float cl[];
+  const int tid = threadIdx.x, nt = blockDim.x, e = blockIdx.y;
+  const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4, Hp = H + 2 * pad, Wp = W + 2 * pad;
+  const int KT = 25 * CIN, G = nt / KT;                 // host picks blockDim so that G >= 1
+  float *tile = cl;                                      // [CIN][Hp][Wp]
+  float *zt = tile + CIN * Hp * Wp;                      // [Ho*Wo][COUT]
+  const bool active = tid < KT * G;
+  const int k = active ? tid % KT : 0, g = active ? tid / KT : 0;
+  const int ci = k % CIN, kw = (k / CIN) % 5, kh = k / (5 * CIN);
+  float acc[COUT], bsum[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) { acc[c] = 0.0f; bsum[c] = 0.0f; }
+  const int b0 = blockIdx.x * ipw, b1 = min(R, b0 + ipw);
+  for (int b = b0; b < b1; ++b) {
+    __syncthreads();
+    const float *src = in + (size_t)e * sE + (size_t)b * sB;
+    for (int i = tid; i < CIN * Hp * Wp; i += nt) {
+      const int xx = i % Wp, yy = (i / Wp) % Hp, c2 = i / (Wp * Hp);
+      const int h = yy - pad, w = xx - pad;
+      tile[i] = (h >= 0 && h < H && w >= 0 && w < W) ? src[h * sH + w * sW + c2 * sC] : 0.0f;
+    }
+    const float *zs = dz + ((size_t)e * R + b) * Ho * Wo * COUT;
+    for (int i = tid; i < Ho * Wo * COUT; i += nt) zt[i] = zs[i];
+    __syncthreads();
+    if (active)
+      for (int p = g; p < Ho * Wo; p += G) {
+        const int y = p / Wo, x = p % Wo;
+        const float v = tile[(ci * Hp + y + kh) * Wp + x + kw];
+        const float *zv = zt + p * COUT;
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) {
+          acc[c] = fmaf(v, zv[c], acc[c]);
+          if (k == 0) bsum[c] += zv[c];
+        }
+      }
+  }
+  // reduce the G pixel groups: red[g][k][COUT] (aliases the tiles), then group 0 adds them up
+  __syncthreads();
+  float *red = cl;
+  if (active && g > 0) {
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) red[((g - 1) * KT + k) * COUT + c] = acc[c];
+    if (k == 0)
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) red[(G - 1) * KT * COUT + (g - 1) * COUT + c] = bsum[c];
+  }
+  __syncthreads();
+  if (active && g == 0) {
+    float *dst = part + ((size_t)e * gridDim.x + blockIdx.x) * (KT * COUT + COUT);
+    for (int gg = 1; gg < G; ++gg)
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) acc[c] += red[((gg - 1) * KT + k) * COUT + c];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) dst[k * COUT + c] = acc[c];
+    if (k == 0) {
+      for (int gg = 1; gg < G; ++gg)
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) bsum[c] += red[(G - 1) * KT * COUT + (gg - 1) * COUT + c];
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) dst[KT * COUT + c] = bsum[c];
+    }
+  }
+}
+
+// slab[e][k_off + i] (+)= sum_wg part[e][wg][i] for the kernel entries, slab[e][b_off + c] for the bias entries
+__global__ __launch_bounds__(256) void k_conv_reduce(const float *part, int nwg, int nk, int ncout, float *slab, long long dp, int k_off, int b_off,
+                                                     int accumulate) {
+  const int e = blockIdx.y, per = nk + ncout;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < per; i += gridDim.x * 256) {
+    float s = 0.0f;
+    for (int wgi = 0; wgi < nwg; ++wgi) s += part[((size_t)e * nwg + wgi) * per + i];
+    float *p = slab + (size_t)e * dp + (i < nk ? k_off + i : b_off + (i - nk));
+    *p = accumulate ? *p + s : s;
+  }
+}
