@@ -139,46 +139,71 @@ __global__ __launch_bounds__(256) void k_conv5_fwd(const float *in, long long sE
 }
 
 // VALID 5x5 conv, gradient w.r.t. the input: din[e][b][yi][xi][ci] = sum_{kh,kw,co} dz[e][b][yi-kh][xi-kw][co] K[kh][kw][ci][co]
-template <int CIN, int COUT>
+// The dZ tiles of NI images share LDS; per kernel tap the CIN x COUT weights are read into registers once and used for
+// every pixel the thread owns (the first version re-read them per pixel and was LDS-issue bound).
+template <int CIN, int COUT, int NI>
 __global__ __launch_bounds__(256) void k_conv5_dx(const float *dz, const float *theta, int k_off, int d, float *din, int R, int Ho, int Wo,
                                                   int ipw) {
   extern __shared__ __attribute__((aligned(16))) float cl[];
   const int tid = threadIdx.x, e = blockIdx.y;
   const int H = Ho + 4, W = Wo + 4, Ht = Ho + 8, Wt = Wo + 8;
   float *Ksh = cl;                         // [25*CIN][COUT]
-  float *tile = Ksh + 25 * CIN * COUT;     // [Ht][Wt][COUT], zero halo of 4
+  float *tile = Ksh + 25 * CIN * COUT;     // [NI][Ht][Wt][COUT], zero halo of 4
   const float *K = theta + (size_t)e * d + k_off;
   for (int i = tid; i < 25 * CIN * COUT; i += 256) Ksh[i] = K[i];
+  const int npix = H * W;
+  constexpr int PPT = 4;                   // pixels per thread and pass
   const int b0 = blockIdx.x * ipw, b1 = min(R, b0 + ipw);
-  for (int b = b0; b < b1; ++b) {
+  for (int bb = b0; bb < b1; bb += NI) {
+    const int ni = min(NI, b1 - bb);
     __syncthreads();
-    const float *src = dz + ((size_t)e * R + b) * Ho * Wo * COUT;
-    for (int i = tid; i < Ht * Wt * COUT; i += 256) {
-      const int c = i % COUT, xx = (i / COUT) % Wt, yy = i / (COUT * Wt);
+    for (int i = tid; i < ni * Ht * Wt * COUT; i += 256) {
+      const int c = i % COUT, xx = (i / COUT) % Wt, yy = (i / (COUT * Wt)) % Ht, im = i / (COUT * Wt * Ht);
       const int y = yy - 4, x = xx - 4;
-      tile[i] = (y >= 0 && y < Ho && x >= 0 && x < Wo) ? src[((size_t)y * Wo + x) * COUT + c] : 0.0f;
+      tile[i] = (y >= 0 && y < Ho && x >= 0 && x < Wo) ? dz[(((size_t)e * R + bb + im) * Ho * Wo + (size_t)y * Wo + x) * COUT + c] : 0.0f;
     }
     __syncthreads();
-    float *dst = din + ((size_t)e * R + b) * H * W * CIN;
-    for (int p = tid; p < H * W; p += 256) {
-      const int yi = p / W, xi = p % W;
-      float acc[CIN];
+    const int total = ni * npix;
+    for (int p0 = tid; p0 < total; p0 += 256 * PPT) {
+      float acc[PPT][CIN];
+      int toff[PPT];
+      bool ok[PPT];
 #pragma unroll
-      for (int ci = 0; ci < CIN; ++ci) acc[ci] = 0.0f;
+      for (int u = 0; u < PPT; ++u) {
+        const int p = p0 + u * 256;
+        ok[u] = p < total;
+        const int pc = ok[u] ? p : 0, im = pc / npix, q = pc % npix;
+        toff[u] = ((im * Ht + q / W + 4) * Wt + q % W + 4) * COUT;
 #pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) acc[u][ci] = 0.0f;
+      }
       for (int kh = 0; kh < 5; ++kh)
-#pragma unroll
         for (int kw = 0; kw < 5; ++kw) {
-          const float *zv = tile + ((yi - kh + 4) * Wt + (xi - kw + 4)) * COUT;
+          float kr[CIN][COUT];
+          const float *kp = Ksh + (kh * 5 + kw) * CIN * COUT;
 #pragma unroll
-          for (int ci = 0; ci < CIN; ++ci) {
-            const float *kr = Ksh + ((kh * 5 + kw) * CIN + ci) * COUT;
+          for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
-            for (int c = 0; c < COUT; ++c) acc[ci] = fmaf(zv[c], kr[c], acc[ci]);
+            for (int c = 0; c < COUT; ++c) kr[ci][c] = kp[ci * COUT + c];
+#pragma unroll
+          for (int u = 0; u < PPT; ++u) {
+            const float *zv = tile + toff[u] - (kh * Wt + kw) * COUT;
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) {
+              const float z = zv[c];
+#pragma unroll
+              for (int ci = 0; ci < CIN; ++ci) acc[u][ci] = fmaf(z, kr[ci][c], acc[u][ci]);
+            }
           }
         }
 #pragma unroll
-      for (int ci = 0; ci < CIN; ++ci) dst[(size_t)p * CIN + ci] = acc[ci];
+      for (int u = 0; u < PPT; ++u)
+        if (ok[u]) {
+          const int p = p0 + u * 256, im = p / npix, q = p % npix;
+          float *dst = din + (((size_t)e * R + bb + im) * npix + q) * CIN;
+#pragma unroll
+          for (int ci = 0; ci < CIN; ++ci) dst[ci] = acc[u][ci];
+        }
     }
   }
 }
