@@ -210,22 +210,27 @@ __global__ __launch_bounds__(256) void k_conv5_dx(const float *dz, const float *
 
 // Kernel / bias gradient of one image range: part[(e * nwg + wg) * (25*CIN*COUT + COUT) + ...]
 //   dK[kh][kw][ci][co] = sum_{b,y,x} in[b][y+kh-pad][x+kw-pad][ci] dz[b][y][x][co],  db[co] = sum dz
-// Thread (k, g): k = (kh, kw, ci) index, g = pixel group; COUT accumulators per thread; groups reduced through LDS.
+// Thread (k5, g): k5 = (kh, ci) owns the five kw taps of a kernel row -- per pixel 5 input reads and one dZ row
+// feed 5*COUT FMAs; g = pixel group; the groups are reduced through LDS at the end.
 template <int COUT>
-__global__ __launch_bounds__(512) void k_conv5_dw(const float *in, long long sE, long long sB, long long sH, long long sW, long long sC, int CIN,
+__global__ __launch_bounds__(256) void k_conv5_dw(const float *in, long long sE, long long sB, long long sH, long long sW, long long sC, int CIN,
                                                   int H, int W, int pad, const float *dz, float *part, int R, int ipw) {
   extern __shared__ __attribute__((aligned(16))) float cl[];
-  const int tid = threadIdx.x, nt = blockDim.x, e = blockIdx.y;
+  const int tid = threadIdx.x, nt = 256, e = blockIdx.y;
   const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4, Hp = H + 2 * pad, Wp = W + 2 * pad;
-  const int KT = 25 * CIN, G = nt / KT;                 // host picks blockDim so that G >= 1
+  const int K5 = 5 * CIN, G = nt / K5;                  // CIN <= 51
   float *tile = cl;                                      // [CIN][Hp][Wp]
   float *zt = tile + CIN * Hp * Wp;                      // [Ho*Wo][COUT]
-  const bool active = tid < KT * G;
-  const int k = active ? tid % KT : 0, g = active ? tid / KT : 0;
-  const int ci = k % CIN, kw = (k / CIN) % 5, kh = k / (5 * CIN);
-  float acc[COUT], bsum[COUT];
+  const bool active = tid < K5 * G;
+  const int k5 = active ? tid % K5 : 0, g = active ? tid / K5 : 0;
+  const int ci = k5 % CIN, kh = k5 / CIN;
+  float acc[5][COUT], bsum[COUT];
 #pragma unroll
-  for (int c = 0; c < COUT; ++c) { acc[c] = 0.0f; bsum[c] = 0.0f; }
+  for (int c = 0; c < COUT; ++c) {
+    bsum[c] = 0.0f;
+#pragma unroll
+    for (int kw = 0; kw < 5; ++kw) acc[kw][c] = 0.0f;
+  }
   const int b0 = blockIdx.x * ipw, b1 = min(R, b0 + ipw);
   for (int b = b0; b < b1; ++b) {
     __syncthreads();
@@ -241,39 +246,51 @@ __global__ __launch_bounds__(512) void k_conv5_dw(const float *in, long long sE,
     if (active)
       for (int p = g; p < Ho * Wo; p += G) {
         const int y = p / Wo, x = p % Wo;
-        const float v = tile[(ci * Hp + y + kh) * Wp + x + kw];
+        const float *tv = tile + (ci * Hp + y + kh) * Wp + x;
         const float *zv = zt + p * COUT;
+        float v[5];
+#pragma unroll
+        for (int kw = 0; kw < 5; ++kw) v[kw] = tv[kw];
 #pragma unroll
         for (int c = 0; c < COUT; ++c) {
-          acc[c] = fmaf(v, zv[c], acc[c]);
-          if (k == 0) bsum[c] += zv[c];
+          const float z = zv[c];
+          if (k5 == 0) bsum[c] += z;
+#pragma unroll
+          for (int kw = 0; kw < 5; ++kw) acc[kw][c] = fmaf(v[kw], z, acc[kw][c]);
         }
       }
   }
-  // reduce the G pixel groups: red[g][k][COUT] (aliases the tiles), then group 0 adds them up
+  // reduce the G pixel groups: red[g-1][k5][5][COUT] (aliases the tiles), then group 0 adds them up
   __syncthreads();
   float *red = cl;
+  const int per_g = K5 * 5 * COUT;
   if (active && g > 0) {
 #pragma unroll
-    for (int c = 0; c < COUT; ++c) red[((g - 1) * KT + k) * COUT + c] = acc[c];
-    if (k == 0)
+    for (int kw = 0; kw < 5; ++kw)
 #pragma unroll
-      for (int c = 0; c < COUT; ++c) red[(G - 1) * KT * COUT + (g - 1) * COUT + c] = bsum[c];
+      for (int c = 0; c < COUT; ++c) red[(g - 1) * per_g + (k5 * 5 + kw) * COUT + c] = acc[kw][c];
+    if (k5 == 0)
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) red[(G - 1) * per_g + (g - 1) * COUT + c] = bsum[c];
   }
   __syncthreads();
   if (active && g == 0) {
-    float *dst = part + ((size_t)e * gridDim.x + blockIdx.x) * (KT * COUT + COUT);
+    float *dst = part + ((size_t)e * gridDim.x + blockIdx.x) * (25 * CIN * COUT + COUT);
     for (int gg = 1; gg < G; ++gg)
 #pragma unroll
-      for (int c = 0; c < COUT; ++c) acc[c] += red[((gg - 1) * KT + k) * COUT + c];
+      for (int kw = 0; kw < 5; ++kw)
 #pragma unroll
-    for (int c = 0; c < COUT; ++c) dst[k * COUT + c] = acc[c];
-    if (k == 0) {
+        for (int c = 0; c < COUT; ++c) acc[kw][c] += red[(gg - 1) * per_g + (k5 * 5 + kw) * COUT + c];
+#pragma unroll
+    for (int kw = 0; kw < 5; ++kw)
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) dst[((kh * 5 + kw) * CIN + ci) * COUT + c] = acc[kw][c];
+    if (k5 == 0) {
       for (int gg = 1; gg < G; ++gg)
 #pragma unroll
-        for (int c = 0; c < COUT; ++c) bsum[c] += red[(G - 1) * KT * COUT + (gg - 1) * COUT + c];
+        for (int c = 0; c < COUT; ++c) bsum[c] += red[(G - 1) * per_g + (gg - 1) * COUT + c];
 #pragma unroll
-      for (int c = 0; c < COUT; ++c) dst[KT * COUT + c] = bsum[c];
+      for (int c = 0; c < COUT; ++c) dst[25 * CIN * COUT + c] = bsum[c];
     }
   }
 }
