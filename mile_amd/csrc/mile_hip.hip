@@ -522,7 +522,7 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
   const size_t lds_max = std::max({lds_f1, lds_w1, lds_f2, lds_x2, lds_w2});
   const bool direct = getenv("MILE_LENET_GEMM") == nullptr && g.C <= 16 && lds_max <= 150 * 1024;
   size_t per = n_a1 + n_p1 + (direct ? 0 : n_col2) + n_a2 + n_p2 + 120 + 84 + g.K;
-  if (grad) per += 84 + 120 + n_p2 + n_a2 + n_p1 + n_a1;
+  if (grad) per += 84 + 120 + n_p2 + n_p1 + (direct ? 0 : n_a2 + n_a1);
   const size_t shared = direct ? 0 : 25 * (size_t)g.C * HW;
   size_t R = ((size_t)1 << 30) / ((size_t)E * per + shared);
   R = std::max<size_t>(1, std::min<size_t>(R, (size_t)N));
@@ -552,7 +552,7 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
   float *col1 = take(R * shared), *a1 = take(ER * n_a1), *p1 = take(ER * n_p1), *col2 = take(direct ? 0 : ER * n_col2), *a2 = take(ER * n_a2);
   float *p2 = take(ER * n_p2), *f1 = take(ER * 120), *f2 = take(ER * 84), *out = take(ER * g.K);
   float *df2 = nullptr, *df1 = nullptr, *dp2 = nullptr, *dz2 = nullptr, *dp1 = nullptr, *dz1 = nullptr;
-  if (grad) { df2 = take(ER * 84); df1 = take(ER * 120); dp2 = take(ER * n_p2); dz2 = take(ER * n_a2); dp1 = take(ER * n_p1); dz1 = take(ER * n_a1); }
+  if (grad) { df2 = take(ER * 84); df1 = take(ER * 120); dp2 = take(ER * n_p2); dz2 = take(direct ? 0 : ER * n_a2); dp1 = take(ER * n_p1); dz1 = take(direct ? 0 : ER * n_a1); }
   float *part1 = take(n_part1), *part2 = take(n_part2);
   if (direct) {
     static bool attr_done = false;
@@ -634,16 +634,15 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
     act_grad(df1, f1, Rc * 120);
     if (dW(g.k_f1, g.b_f1, g.flat, 120, p2, Rc * g.flat, df1, Rc)) return fail(MILE_ERR_HIP, "rocblas sgemm (d fc1) failed");
     if (dX(g.k_f1, g.flat, 120, df1, Rc, dp2)) return fail(MILE_ERR_HIP, "rocblas sgemm (d fc1 in) failed");
-    k_unpool_actgrad<<<blocks(B * (long long)n_a2), 256, 0, st>>>(dp2, a2, dz2, B, g.h2, g.w2, 16, act);
-    if (direct) {
+    if (!direct) k_unpool_actgrad<<<blocks(B * (long long)n_a2), 256, 0, st>>>(dp2, a2, dz2, B, g.h2, g.w2, 16, act);
+    if (direct) {   // dZ = unpool(dP) * act'(A) is formed inside the kernels' tile loads: no dz2 / dz1 arrays
       const int acc = chunk != 0;
-      k_conv5_dw<16><<<dim3(nwg, E), 256, lds_w2, st>>>(p1, Rc * (long long)n_p1, (long long)n_p1, g.wp1 * 6, 6, 1, 6, g.hp1, g.wp1, 0, dz2,
-                                                       part2, (int)Rc, ipw);
+      k_conv5_dw<16><<<dim3(nwg, E), 256, lds_w2, st>>>(p1, Rc * (long long)n_p1, (long long)n_p1, g.wp1 * 6, 6, 1, 6, g.hp1, g.wp1, 0, dp2, a2,
+                                                       act, part2, (int)Rc, ipw);
       k_conv_reduce<<<dim3(10, E), 256, 0, st>>>(part2, (int)nwg, 2400, 16, slab, dp, g.k_c2, g.b_c2, acc);
-      k_conv5_dx<6, 16, 4><<<dim3(nwg, E), 256, lds_x2, st>>>(dz2, theta, g.k_c2, d, dp1, (int)Rc, g.h2, g.w2, ipw);
-      k_unpool_actgrad<<<blocks(B * (long long)n_a1), 256, 0, st>>>(dp1, a1, dz1, B, g.H, g.W, 6, act);
-      k_conv5_dw<6><<<dim3(nwg, E), 256, lds_w1, st>>>(Xc, 0, (long long)g.C * HW, g.W, 1, (long long)HW, g.C, g.H, g.W, 2, dz1, part1, (int)Rc,
-                                                      ipw);
+      k_conv5_dx<6, 16, 4><<<dim3(nwg, E), 256, lds_x2, st>>>(dp2, a2, act, theta, g.k_c2, d, dp1, (int)Rc, g.h2, g.w2, ipw);
+      k_conv5_dw<6><<<dim3(nwg, E), 256, lds_w1, st>>>(Xc, 0, (long long)g.C * HW, g.W, 1, (long long)HW, g.C, g.H, g.W, 2, dp1, a1, act, part1,
+                                                      (int)Rc, ipw);
       k_conv_reduce<<<dim3(2, E), 256, 0, st>>>(part1, (int)nwg, KT1 * 6, 6, slab, dp, g.k_c1, g.b_c1, acc);
     } else {
       if (dW(g.k_c2, g.b_c2, 150, 16, col2, M2 * 150, dz2, M2)) return fail(MILE_ERR_HIP, "rocblas sgemm (d conv2) failed");

@@ -88,6 +88,16 @@ __global__ __launch_bounds__(256) void k_col2im5(const float *dcol, float *dst, 
 // input (zero-padded) and, for the gradients, its dZ are staged in LDS tiles.  NHWC activations
 // [E][R][H][W][C]; the first layer's input is the shared NCHW image chunk (general strides, particle stride 0).
 // ------------------------------------------------------------------------------------------------------
+// dZ of a conv layer's output, formed on the fly from the pooled gradient and the activation output:
+// dz[y][x][c] = (avg-pool backward: dp[y/2][x/2][c] / 4, zero on the cropped border) * act'(a[y][x][c])
+__device__ __forceinline__ float dz_from_pool(const float *dp_img, const float *a_img, int y, int x, int c, int Ho, int Wo, int C,
+                                              int activation) {
+  const int Hq = Ho / 2, Wq = Wo / 2;
+  float g = 0.0f;
+  if (y < 2 * Hq && x < 2 * Wq) g = 0.25f * dp_img[((y >> 1) * Wq + (x >> 1)) * C + c];
+  return g * act_bwd(activation, a_img[(y * Wo + x) * C + c]);
+}
+
 template <int COUT>
 struct ConvPad { static constexpr int P = (COUT + 3) / 4 * 4; };
 
@@ -142,8 +152,8 @@ __global__ __launch_bounds__(256) void k_conv5_fwd(const float *in, long long sE
 // The dZ tiles of NI images share LDS; per kernel tap the CIN x COUT weights are read into registers once and used for
 // every pixel the thread owns (the first version re-read them per pixel and was LDS-issue bound).
 template <int CIN, int COUT, int NI>
-__global__ __launch_bounds__(256) void k_conv5_dx(const float *dz, const float *theta, int k_off, int d, float *din, int R, int Ho, int Wo,
-                                                  int ipw) {
+__global__ __launch_bounds__(256) void k_conv5_dx(const float *dp, const float *a, int activation, const float *theta, int k_off, int d,
+                                                  float *din, int R, int Ho, int Wo, int ipw) {
   extern __shared__ __attribute__((aligned(16))) float cl[];
   const int tid = threadIdx.x, e = blockIdx.y;
   const int H = Ho + 4, W = Wo + 4, Ht = Ho + 8, Wt = Wo + 8;
@@ -160,7 +170,10 @@ __global__ __launch_bounds__(256) void k_conv5_dx(const float *dz, const float *
     for (int i = tid; i < ni * Ht * Wt * COUT; i += 256) {
       const int c = i % COUT, xx = (i / COUT) % Wt, yy = (i / (COUT * Wt)) % Ht, im = i / (COUT * Wt * Ht);
       const int y = yy - 4, x = xx - 4;
-      tile[i] = (y >= 0 && y < Ho && x >= 0 && x < Wo) ? dz[(((size_t)e * R + bb + im) * Ho * Wo + (size_t)y * Wo + x) * COUT + c] : 0.0f;
+      const size_t img = (size_t)e * R + bb + im;
+      tile[i] = (y >= 0 && y < Ho && x >= 0 && x < Wo)
+                    ? dz_from_pool(dp + img * (Ho / 2) * (Wo / 2) * COUT, a + img * Ho * Wo * COUT, y, x, c, Ho, Wo, COUT, activation)
+                    : 0.0f;
     }
     __syncthreads();
     const int total = ni * npix;
@@ -214,7 +227,8 @@ __global__ __launch_bounds__(256) void k_conv5_dx(const float *dz, const float *
 // feed 5*COUT FMAs; g = pixel group; the groups are reduced through LDS at the end.
 template <int COUT>
 __global__ __launch_bounds__(256) void k_conv5_dw(const float *in, long long sE, long long sB, long long sH, long long sW, long long sC, int CIN,
-                                                  int H, int W, int pad, const float *dz, float *part, int R, int ipw) {
+                                                  int H, int W, int pad, const float *dp, const float *a, int activation, float *part, int R,
+                                                  int ipw) {
   extern __shared__ __attribute__((aligned(16))) float cl[];
   const int tid = threadIdx.x, nt = 256, e = blockIdx.y;
   const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4, Hp = H + 2 * pad, Wp = W + 2 * pad;
@@ -240,8 +254,12 @@ __global__ __launch_bounds__(256) void k_conv5_dw(const float *in, long long sE,
       const int h = yy - pad, w = xx - pad;
       tile[i] = (h >= 0 && h < H && w >= 0 && w < W) ? src[h * sH + w * sW + c2 * sC] : 0.0f;
     }
-    const float *zs = dz + ((size_t)e * R + b) * Ho * Wo * COUT;
-    for (int i = tid; i < Ho * Wo * COUT; i += nt) zt[i] = zs[i];
+    const size_t img = (size_t)e * R + b;
+    const float *dp_img = dp + img * (Ho / 2) * (Wo / 2) * COUT, *a_img = a + img * Ho * Wo * COUT;
+    for (int i = tid; i < Ho * Wo * COUT; i += nt) {
+      const int c = i % COUT, px = i / COUT;
+      zt[i] = dz_from_pool(dp_img, a_img, px / Wo, px % Wo, c, Ho, Wo, COUT, activation);
+    }
     __syncthreads();
     if (active)
       for (int p = g; p < Ho * Wo; p += G) {
