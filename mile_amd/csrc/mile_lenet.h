@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void k_conv5_dx(const float *dp, const float *
   const float *K = theta + (size_t)e * d + k_off;
   for (int i = tid; i < 25 * CIN * COUT; i += 256) Ksh[i] = K[i];
   const int npix = H * W;
-  constexpr int PPT = 4;                   // pixels per thread and pass
+  constexpr int PPT = NI;                  // pixels per thread and pass (NI images x ~200 pixels over 256 threads)
   const int b0 = blockIdx.x * ipw, b1 = min(R, b0 + ipw);
   for (int bb = b0; bb < b1; bb += NI) {
     const int ni = min(NI, b1 - bb);

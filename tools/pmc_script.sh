@@ -21,7 +21,7 @@ for f in glob.glob(out + '/p*/*/*counter_collection.csv'):
         k = r['Kernel_Name'].split('(')[0][:40]
         agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, cs in agg.items():
-    if 'k_grad' not in k: continue
+    if not any(t in k for t in ("k_grad", "k_conv5")): continue
     print(k)
     for c, v in sorted(cs.items()):
         print(f'   {c:32s} n={len(v):4d} mean={sum(v)/len(v):16.1f}')
