@@ -515,10 +515,10 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
   const int ipw = 8;                                                  // images per workgroup
   const size_t lds_f1 = (size_t)(25 * g.C * 8 + 8 + g.C * (g.H + 4) * (g.W + 4)) * 4;
   const int KT1 = 25 * g.C;
-  const size_t G1 = 256 / (5 * g.C), G2 = 256 / 30;                  // k_conv5_dw pixel groups; their partial sums alias the tiles at the end
-  const size_t lds_w1 = std::max((size_t)(g.C * (g.H + 4) * (g.W + 4)) + HW * 6, (G1 - 1) * (size_t)(KT1 * 6) + G1 * 6) * 4;
-  const size_t lds_f2 = (size_t)(150 * 16 + 16 + 6 * P1) * 4, lds_x2 = (size_t)(2400 + 2 * (g.h2 + 8) * (g.w2 + 8) * 16) * 4;   // 2 images' dZ per pass: two workgroups per CU
-  const size_t lds_w2 = std::max(6 * P1 + HW2 * 16, (G2 - 1) * (size_t)2400 + G2 * 16) * 4;
+  // k_conv5_dw: pixel groups are reduced 3 at a time through LDS (buffer aliases the tiles)
+  const size_t lds_w1 = std::max((size_t)(g.C * (g.H + 4) * (g.W + 4)) + HW * 6, 3 * (size_t)(KT1 * 6 + 6)) * 4;
+  const size_t lds_f2 = (size_t)(150 * 16 + 16 + 6 * P1) * 4, lds_x2 = (size_t)(2400 + 1 * (g.h2 + 8) * (g.w2 + 8) * 16) * 4;   // 2 images' dZ per pass: two workgroups per CU
+  const size_t lds_w2 = std::max(6 * P1 + HW2 * 16, 3 * (size_t)(2400 + 16)) * 4;
   const size_t lds_max = std::max({lds_f1, lds_w1, lds_f2, lds_x2, lds_w2});
   const bool direct = getenv("MILE_LENET_GEMM") == nullptr && g.C <= 16 && lds_max <= 150 * 1024;
   size_t per = n_a1 + n_p1 + (direct ? 0 : n_col2) + n_a2 + n_p2 + 120 + 84 + g.K;
@@ -561,7 +561,7 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
       HIP_TRY(hipFuncSetAttribute((const void *)k_conv5_fwd<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void *)k_conv5_dw<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void *)k_conv5_dw<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      HIP_TRY(hipFuncSetAttribute((const void *)k_conv5_dx<6, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void *)k_conv5_dx<6, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
       attr_done = true;
     }
   }
@@ -640,7 +640,7 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
       k_conv5_dw<16><<<dim3(nwg, E), 256, lds_w2, st>>>(p1, Rc * (long long)n_p1, (long long)n_p1, g.wp1 * 6, 6, 1, 6, g.hp1, g.wp1, 0, dp2, a2,
                                                        act, part2, (int)Rc, ipw);
       k_conv_reduce<<<dim3(10, E), 256, 0, st>>>(part2, (int)nwg, 2400, 16, slab, dp, g.k_c2, g.b_c2, acc);
-      k_conv5_dx<6, 16, 2><<<dim3(nwg, E), 256, lds_x2, st>>>(dp2, a2, act, theta, g.k_c2, d, dp1, (int)Rc, g.h2, g.w2, ipw);
+      k_conv5_dx<6, 16, 1><<<dim3(nwg, E), 256, lds_x2, st>>>(dp2, a2, act, theta, g.k_c2, d, dp1, (int)Rc, g.h2, g.w2, ipw);
       k_conv5_dw<6><<<dim3(nwg, E), 256, lds_w1, st>>>(Xc, 0, (long long)g.C * HW, g.W, 1, (long long)HW, g.C, g.H, g.W, 2, dp1, a1, act, part1,
                                                       (int)Rc, ipw);
       k_conv_reduce<<<dim3(2, E), 256, 0, st>>>(part1, (int)nwg, KT1 * 6, 6, slab, dp, g.k_c1, g.b_c1, acc);

@@ -278,38 +278,45 @@ __global__ __launch_bounds__(256) void k_conv5_dw(const float *in, long long sE,
         }
       }
   }
-  // reduce the G pixel groups: red[g-1][k5][5][COUT] (aliases the tiles), then group 0 adds them up
-  __syncthreads();
-  float *red = cl;
+  // reduce the G pixel groups into group 0, RG groups per round through a small LDS buffer (aliases the tiles):
+  // red[RG][k5][5][COUT] + red_b[RG][COUT].  A buffer for all groups at once would cost the kernel its occupancy.
+  constexpr int RG = 3;
   const int per_g = K5 * 5 * COUT;
-  if (active && g > 0) {
-#pragma unroll
-    for (int kw = 0; kw < 5; ++kw)
-#pragma unroll
-      for (int c = 0; c < COUT; ++c) red[(g - 1) * per_g + (k5 * 5 + kw) * COUT + c] = acc[kw][c];
-    if (k5 == 0)
-#pragma unroll
-      for (int c = 0; c < COUT; ++c) red[(G - 1) * per_g + (g - 1) * COUT + c] = bsum[c];
-  }
-  __syncthreads();
-  if (active && g == 0) {
-    float *dst = part + ((size_t)e * gridDim.x + blockIdx.x) * (25 * CIN * COUT + COUT);
-    for (int gg = 1; gg < G; ++gg)
+  float *red = cl, *red_b = cl + RG * per_g;
+  for (int base = 1; base < G; base += RG) {
+    __syncthreads();
+    if (active && g >= base && g < base + RG) {
 #pragma unroll
       for (int kw = 0; kw < 5; ++kw)
 #pragma unroll
-        for (int c = 0; c < COUT; ++c) acc[kw][c] += red[(gg - 1) * per_g + (k5 * 5 + kw) * COUT + c];
+        for (int c = 0; c < COUT; ++c) red[(g - base) * per_g + (k5 * 5 + kw) * COUT + c] = acc[kw][c];
+      if (k5 == 0)
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) red_b[(g - base) * COUT + c] = bsum[c];
+    }
+    __syncthreads();
+    if (active && g == 0) {
+      const int ng = min(RG, G - base);
+      for (int gg = 0; gg < ng; ++gg) {
+#pragma unroll
+        for (int kw = 0; kw < 5; ++kw)
+#pragma unroll
+          for (int c = 0; c < COUT; ++c) acc[kw][c] += red[gg * per_g + (k5 * 5 + kw) * COUT + c];
+        if (k5 == 0)
+#pragma unroll
+          for (int c = 0; c < COUT; ++c) bsum[c] += red_b[gg * COUT + c];
+      }
+    }
+  }
+  if (active && g == 0) {
+    float *dst = part + ((size_t)e * gridDim.x + blockIdx.x) * (25 * CIN * COUT + COUT);
 #pragma unroll
     for (int kw = 0; kw < 5; ++kw)
 #pragma unroll
       for (int c = 0; c < COUT; ++c) dst[((kh * 5 + kw) * CIN + ci) * COUT + c] = acc[kw][c];
-    if (k5 == 0) {
-      for (int gg = 1; gg < G; ++gg)
-#pragma unroll
-        for (int c = 0; c < COUT; ++c) bsum[c] += red[(G - 1) * per_g + (gg - 1) * COUT + c];
+    if (k5 == 0)
 #pragma unroll
       for (int c = 0; c < COUT; ++c) dst[25 * CIN * COUT + c] = bsum[c];
-    }
   }
 }
 
