@@ -54,8 +54,13 @@ def test_lenet_logpost_grad_matches_oracle(LN, C, H, W, K, act, task, prior, N, 
         assert _relerr(g[:, off:off + n], g_ref[:, off:off + n]) < 5e-5, name
 
 
-def test_lenet_image_chunks_accumulate(LN, monkeypatch):
+@pytest.mark.parametrize('gemm_form', [False, True])
+def test_lenet_image_chunks_accumulate(LN, monkeypatch, gemm_form):
+    """Images are walked in chunks (forced to 4 here); both forms of the convolution half: the direct LDS-tile kernels
+    and the im2col + strided-batched SGEMM form kept as fallback for images too large for the tiles."""
     monkeypatch.setenv('MILE_GEMM_ROWS', '4')
+    if gemm_form:
+        monkeypatch.setenv('MILE_LENET_GEMM', '1')
     ospec = LN.LeNetSpec(3, 16, 20, 5)
     prob = LN.synthetic_problem(ospec, 11, 3, seed=5)
     lp_ref, g_ref = LN.logpost_and_grad(ospec, prob['theta0'].astype(np.float64), prob['X'], prob['y'])
