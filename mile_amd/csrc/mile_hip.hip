@@ -512,7 +512,7 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
   const size_t n_a1 = 6 * HW, n_p1 = 6 * P1, n_col2 = 150 * HW2, n_a2 = 16 * HW2, n_p2 = g.flat;
   // direct convolution kernels (LDS tiles per image) unless the image is too large for them or the im2col + SGEMM
   // form is asked for (MILE_LENET_GEMM=1: kept as the second implementation / fallback)
-  const int ipw = 8;                                                  // images per workgroup
+  const int ipw = getenv("MILE_LENET_IPW") ? std::max(1, atoi(getenv("MILE_LENET_IPW"))) : 8;   // images per workgroup (dev knob)
   const size_t lds_f1 = (size_t)(25 * g.C * 8 + 8 + g.C * (g.H + 4) * (g.W + 4)) * 4;
   const int KT1 = 25 * g.C;
   // k_conv5_dw: pixel groups are reduced 3 at a time through LDS (buffer aliases the tiles)

@@ -128,3 +128,24 @@ def test_train_cli_lenet_yaml(tmp_path):
     import json
     m = json.loads((exp / 'metrics.json').read_text())
     assert m['split'] == 'valid' and m['n_points'] == 30 and np.isfinite(m['lppd'])
+
+
+def test_hip_reproduces_committed_golden_fixtures(LN, oracle):
+    """The committed fixtures of tests/golden/make_golden_r01b.py: LeNet gradient (fp32 vs fp64 fixture) and the
+    bf16-operand recipe of k_grad_w128b."""
+    from pathlib import Path
+    from mile_amd import ModelSpec
+    from mile_amd.engine import Engine
+    gold = Path(__file__).parent / 'golden'
+    z = np.load(gold / 'lenet_2x12x14.npz')
+    ls = LN.LeNetSpec(2, 12, 14, 3, activation='tanh')
+    eng = _engine(ls, {'X': z['X'], 'y': z['y']})
+    lp, g = eng.logpost_grad(torch.from_numpy(z['theta0']))
+    assert _relerr(lp.cpu().numpy(), z['logp']) < 2e-5 and _relerr(g.cpu().numpy(), z['grad']) < 5e-5
+    z = np.load(gold / 'bf16_recipe_128x2.npz')
+    spec = ModelSpec(9, (128, 128, 2))
+    eng = Engine(spec, torch.from_numpy(z['X']), torch.from_numpy(z['y']), device='cuda:0', grad_kernel='mfma_w128_bf16')
+    lp, g = eng.logpost_grad(torch.from_numpy(z['theta0']))
+    assert _relerr(lp.cpu().numpy(), z['logp']) < 1e-4
+    err = np.linalg.norm(g.cpu().numpy().astype(np.float64) - z['grad'], axis=1) / z['grad_norm']
+    assert err.max() < 5e-3, err

@@ -309,3 +309,18 @@ def test_lenet_oracle_matches_torch_autograd(C, H, W, K, act, task):
         assert abs(tot.item() - lp[e]) < 1e-9 * abs(lp[e])
         assert np.abs(t.grad.numpy() - g[e]).max() < 1e-9 * np.abs(g[e]).max()
     assert spec.n_params == {(1, 28, 28, 10): 61706, (3, 32, 32, 10): 83126}.get((C, H, W, K), spec.n_params)
+
+
+def test_golden_bf16_recipe_and_lenet():
+    """Committed outputs of the two later restatements (tests/golden/make_golden_r01b.py)."""
+    from oracle import lenet_oracle as LN
+    z = np.load(GOLD / 'bf16_recipe_128x2.npz')
+    spec = O.ModelSpec(9, (128, 128, 2))
+    lp, g = O.logpost_and_grad_bf16(spec, z['theta0'].astype(np.float64), z['X'], z['y'])
+    assert np.allclose(lp, z['logp'], rtol=1e-12, atol=0)
+    assert np.abs(g - z['grad']).max() <= 1e-6 * np.abs(z['grad']).max()        # grad stored as float32
+    assert np.allclose(np.linalg.norm(g, axis=1), z['grad_norm'], rtol=1e-12)
+    z = np.load(GOLD / 'lenet_2x12x14.npz')
+    ls = LN.LeNetSpec(2, 12, 14, 3, activation='tanh')
+    lp, g = LN.logpost_and_grad(ls, z['theta0'].astype(np.float64), z['X'], z['y'])
+    assert np.allclose(lp, z['logp'], rtol=1e-12, atol=0) and np.allclose(g, z['grad'], rtol=1e-10, atol=1e-12)
