@@ -520,6 +520,8 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
   const size_t lds_f2 = (size_t)(150 * 16 + 16 + 6 * P1) * 4, lds_x2 = (size_t)(2400 + 1 * (g.h2 + 8) * (g.w2 + 8) * 16) * 4;   // 2 images' dZ per pass: two workgroups per CU
   const size_t lds_w2 = std::max(6 * P1 + HW2 * 16, 3 * (size_t)(2400 + 16)) * 4;
   const size_t lds_max = std::max({lds_f1, lds_w1, lds_f2, lds_x2, lds_w2});
+  // compile-time geometry for CIFAR- / MNIST-sized inputs (their LDS needs are below the 64 KiB default limit)
+  const int geo = (g.C == 3 && g.H == 32 && g.W == 32) ? 1 : (g.C == 1 && g.H == 28 && g.W == 28) ? 3 : 0;
   const bool direct = getenv("MILE_LENET_GEMM") == nullptr && g.C <= 16 && lds_max <= 150 * 1024;
   size_t per = n_a1 + n_p1 + (direct ? 0 : n_col2) + n_a2 + n_p2 + 120 + 84 + g.K;
   if (grad) per += 84 + 120 + n_p2 + n_p1 + (direct ? 0 : n_a2 + n_a1);
@@ -557,11 +559,11 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
   if (direct) {
     static bool attr_done = false;
     if (!attr_done) {
-      HIP_TRY(hipFuncSetAttribute((const void *)k_conv5_fwd<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      HIP_TRY(hipFuncSetAttribute((const void *)k_conv5_fwd<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      HIP_TRY(hipFuncSetAttribute((const void *)k_conv5_dw<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      HIP_TRY(hipFuncSetAttribute((const void *)k_conv5_dw<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      HIP_TRY(hipFuncSetAttribute((const void *)k_conv5_dx<6, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void *)k_conv5_fwd<6, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void *)k_conv5_fwd<16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void *)k_conv5_dw<6, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void *)k_conv5_dw<16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void *)k_conv5_dx<6, 16, 1, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
       attr_done = true;
     }
   }
@@ -582,11 +584,13 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
     const float *Xc = X + (size_t)r0 * g.C * HW;
     const unsigned nwg = (unsigned)((Rc + ipw - 1) / ipw);
     if (direct) {
-      k_conv5_fwd<6><<<dim3(nwg, E), 256, lds_f1, st>>>(Xc, 0, (long long)g.C * HW, g.W, 1, (long long)HW, g.C, g.H, g.W, 2, theta, g.k_c1,
-                                                       g.b_c1, d, a1, (int)Rc, ipw, act);
+#define LAUNCH_FWD1(GEO_) k_conv5_fwd<6, GEO_><<<dim3(nwg, E), 256, lds_f1, st>>>(Xc, 0, (long long)g.C * HW, g.W, 1, (long long)HW, g.C, g.H, g.W, 2, theta, g.k_c1, g.b_c1, d, a1, (int)Rc, ipw, act)
+#define LAUNCH_FWD2(GEO_) k_conv5_fwd<16, GEO_><<<dim3(nwg, E), 256, lds_f2, st>>>(p1, Rc * (long long)n_p1, (long long)n_p1, g.wp1 * 6, 6, 1, 6, g.hp1, g.wp1, 0, theta, g.k_c2, g.b_c2, d, a2, (int)Rc, ipw, act)
+      if (geo == 1) LAUNCH_FWD1(1); else if (geo == 3) LAUNCH_FWD1(3); else LAUNCH_FWD1(0);
       k_avgpool2<<<blocks(B * (long long)n_p1), 256, 0, st>>>(a1, p1, B, g.H, g.W, 6);
-      k_conv5_fwd<16><<<dim3(nwg, E), 256, lds_f2, st>>>(p1, Rc * (long long)n_p1, (long long)n_p1, g.wp1 * 6, 6, 1, 6, g.hp1, g.wp1, 0, theta,
-                                                        g.k_c2, g.b_c2, d, a2, (int)Rc, ipw, act);
+      if (geo == 1) LAUNCH_FWD2(2); else if (geo == 3) LAUNCH_FWD2(4); else LAUNCH_FWD2(0);
+#undef LAUNCH_FWD1
+#undef LAUNCH_FWD2
     } else {
       k_im2col5<<<blocks(M1 * 25 * g.C), 256, 0, st>>>(Xc, col1, Rc, g.H, g.W, g.C, g.H, g.W, 2, (long long)g.C * HW, g.W, 1, (long long)HW);
       if (fwd(g.k_c1, 25 * g.C, 6, col1, 0, M1, a1)) return fail(MILE_ERR_HIP, "rocblas sgemm (conv1) failed");
@@ -637,12 +641,16 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
     if (!direct) k_unpool_actgrad<<<blocks(B * (long long)n_a2), 256, 0, st>>>(dp2, a2, dz2, B, g.h2, g.w2, 16, act);
     if (direct) {   // dZ = unpool(dP) * act'(A) is formed inside the kernels' tile loads: no dz2 / dz1 arrays
       const int acc = chunk != 0;
-      k_conv5_dw<16><<<dim3(nwg, E), 256, lds_w2, st>>>(p1, Rc * (long long)n_p1, (long long)n_p1, g.wp1 * 6, 6, 1, 6, g.hp1, g.wp1, 0, dp2, a2,
-                                                       act, part2, (int)Rc, ipw);
+#define LAUNCH_DW2(GEO_) k_conv5_dw<16, GEO_><<<dim3(nwg, E), 256, lds_w2, st>>>(p1, Rc * (long long)n_p1, (long long)n_p1, g.wp1 * 6, 6, 1, 6, g.hp1, g.wp1, 0, dp2, a2, act, part2, (int)Rc, ipw)
+#define LAUNCH_DX(HO_, WO_) k_conv5_dx<6, 16, 1, HO_, WO_><<<dim3(nwg, E), 256, lds_x2, st>>>(dp2, a2, act, theta, g.k_c2, d, dp1, (int)Rc, g.h2, g.w2, ipw)
+#define LAUNCH_DW1(GEO_) k_conv5_dw<6, GEO_><<<dim3(nwg, E), 256, lds_w1, st>>>(Xc, 0, (long long)g.C * HW, g.W, 1, (long long)HW, g.C, g.H, g.W, 2, dp1, a1, act, part1, (int)Rc, ipw)
+      if (geo == 1) LAUNCH_DW2(2); else if (geo == 3) LAUNCH_DW2(4); else LAUNCH_DW2(0);
       k_conv_reduce<<<dim3(10, E), 256, 0, st>>>(part2, (int)nwg, 2400, 16, slab, dp, g.k_c2, g.b_c2, acc);
-      k_conv5_dx<6, 16, 1><<<dim3(nwg, E), 256, lds_x2, st>>>(dp2, a2, act, theta, g.k_c2, d, dp1, (int)Rc, g.h2, g.w2, ipw);
-      k_conv5_dw<6><<<dim3(nwg, E), 256, lds_w1, st>>>(Xc, 0, (long long)g.C * HW, g.W, 1, (long long)HW, g.C, g.H, g.W, 2, dp1, a1, act, part1,
-                                                      (int)Rc, ipw);
+      if (geo == 1) LAUNCH_DX(12, 12); else if (geo == 3) LAUNCH_DX(10, 10); else LAUNCH_DX(0, 0);
+      if (geo == 1) LAUNCH_DW1(1); else if (geo == 3) LAUNCH_DW1(3); else LAUNCH_DW1(0);
+#undef LAUNCH_DW2
+#undef LAUNCH_DX
+#undef LAUNCH_DW1
       k_conv_reduce<<<dim3(2, E), 256, 0, st>>>(part1, (int)nwg, KT1 * 6, 6, slab, dp, g.k_c1, g.b_c1, acc);
     } else {
       if (dW(g.k_c2, g.b_c2, 150, 16, col2, M2 * 150, dz2, M2)) return fail(MILE_ERR_HIP, "rocblas sgemm (d conv2) failed");
