@@ -21,6 +21,8 @@ def main():
     ap.add_argument('--exp', '-e', required=True, help='experiment directory (holds config.yaml and samples/)')
     ap.add_argument('--split', default='test', choices=['train', 'valid', 'test'])
     ap.add_argument('--device', default='cuda:0')
+    ap.add_argument('--drop-nonfinite', action='store_true',
+                    help='leave out chains with non-finite samples (the reference would report NaN; default: keep them)')
     args = ap.parse_args()
     exp = Path(args.exp)
     from mile_amd.callbacks import load_samples_from_dir
@@ -32,6 +34,9 @@ def main():
     tr.build_model(cfg)
     spec = tr.prob_model.spec
     samples = load_samples_from_dir(exp / cfg.training.sampler._dir_name, spec)       # [C, S, d]
+    bad_chains = ~np.isfinite(samples).all(axis=(1, 2))
+    if args.drop_nonfinite and bad_chains.any() and not bad_chains.all():
+        samples = samples[~bad_chains]
     x = getattr(tr.loader, f'{args.split}_x')
     y = getattr(tr.loader, f'{args.split}_y')
     x = np.ascontiguousarray(x).reshape(len(x), -1)
@@ -42,7 +47,7 @@ def main():
            'n_samples': int(samples.shape[1]), 'n_points': int(x.shape[0]),
            'lppd': float(lppd(pw).item()), 'nll_mean': float(-pw.mean().item()),
            'running_lppd_last': float(running_lppd(pw)[-1].item()),
-           'nonfinite_samples': int((~torch.isfinite(torch.from_numpy(samples)).all(dim=-1)).sum().item())}
+           'nonfinite_chains_total': int(bad_chains.sum()), 'nonfinite_samples': int((~torch.isfinite(torch.from_numpy(samples)).all(dim=-1)).sum().item())}
     (exp / 'metrics.json').write_text(json.dumps(out, indent=1) + '\n')
     print(json.dumps(out))
 
