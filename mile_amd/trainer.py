@@ -110,18 +110,42 @@ class BDETrainer:
     def train_bde(self):
         with measure_time('time.warmstart'):
             self.train_warmstart()
+        if self.world_size > 1:                       # rank 0 wrote the members every rank starts from
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                mdist.init_process_group()
+            dist.barrier()
         self.start_sampling()
 
     def train_warmstart(self):
+        """trainer.py:330-392: train the deep-ensemble members the chains start from (mile_amd/warmstart.py: the
+        reference's optimizer, epoch / validation / early-stopping schedule, full-batch gradients from the HIP engine),
+        or reuse the members of `warmstart_exp_dir`; with `include: false` the chains start from module.init-style
+        random parameters."""
         ws = self.config.training.warmstart
-        if ws.include and not ws.warmstart_exp_dir:
-            logger.warning('\t| warm-start training (optax deep ensemble) is outside the MI355X hot path: '
-                           'chains start from module.init-style random parameters; set warmstart_exp_dir to reuse trained members.')
+        if ws.warmstart_exp_dir or self.rank != 0:
+            return
         wdir = self.exp_dir / ws._dir_name
-        if self.rank == 0 and not ws.warmstart_exp_dir:
-            params = self.init_module_params(range(self.n_chains))
-            for i in range(self.n_chains):
-                save_params(wdir, self.prob_model.spec, params[i], i)
+        params = self.init_module_params(range(self.n_chains))
+        if ws.include:
+            from mile_amd.warmstart import train_deep_ensemble
+            tx = np.ascontiguousarray(self.loader.train_x).reshape(len(self.loader.train_x), -1)
+            x, y = torch.from_numpy(tx), torch.from_numpy(np.ascontiguousarray(self.loader.train_y))
+            eng = self.prob_model.engine(x, y)
+            vx = np.ascontiguousarray(self.loader.valid_x).reshape(len(self.loader.valid_x), -1)
+            logger.info(f'\t| Starting Training Warmstart for chains {list(range(self.n_chains))}')
+            theta, hist = train_deep_ensemble(
+                eng, self.prob_model.prior, torch.from_numpy(params), n_train=len(tx),
+                valid_x=torch.from_numpy(vx) if len(vx) else None,
+                valid_y=torch.from_numpy(np.ascontiguousarray(self.loader.valid_y)) if len(vx) else None,
+                optimizer=ws.optimizer_config.name, optimizer_parameters=ws.optimizer_config.parameters,
+                max_epochs=ws.max_epochs, batch_size=ws.batch_size, patience=ws.patience)
+            params = theta.cpu().numpy()
+            self._engine_inputs = (x, y)               # the sampler reuses the same engine (keyed by tensor identity)
+            logger.info(f"\t| Warmstart Training completed after {hist['epochs']} epochs "
+                        f"({int(hist['stopped'].sum())}/{self.n_chains} members stopped early)")
+        for i in range(self.n_chains):
+            save_params(wdir, self.prob_model.spec, params[i], i)
 
     def start_sampling(self):
         """trainer.py:543-607 (full-batch, non-partition branch)."""
@@ -134,8 +158,11 @@ class BDETrainer:
             if warm_path.exists():
                 chains = sorted((warm_path / i for i in os.listdir(warm_path) if i.startswith('params')),
                                 key=lambda p: int(p.stem.split('_')[-1]))
-            x = torch.from_numpy(np.ascontiguousarray(self.loader.train_x).reshape(len(self.loader.train_x), -1))
-            y = torch.from_numpy(np.ascontiguousarray(self.loader.train_y))
+            if getattr(self, '_engine_inputs', None) is not None:
+                x, y = self._engine_inputs
+            else:
+                x = torch.from_numpy(np.ascontiguousarray(self.loader.train_x).reshape(len(self.loader.train_x), -1))
+                y = torch.from_numpy(np.ascontiguousarray(self.loader.train_y))
             log_post = self.prob_model.bind(x, y)
             for step in self.train_plan:
                 mine = mdist.shard_chains(step, self.world_size, self.rank)

@@ -345,6 +345,29 @@ def test_train_cli_runs_the_yaml_surface(tmp_path):
     assert np.isfinite(m['lppd']) and np.isfinite(m['nll_mean']) and m['lppd'] >= -m['nll_mean'] - 1e-6   # Jensen
 
 
+def test_train_cli_with_warmstart_training(tmp_path):
+    """`warmstart.include: true`: the deep-ensemble members are trained (reference optimizer / epoch / early-stopping
+    schedule on full-batch engine gradients) and the chains start from them."""
+    import yaml
+    cfg = yaml.safe_load((ROOT / 'experiments' / 'smoke_synthetic.yaml').read_text())
+    cfg['saving_dir'] = str(tmp_path)
+    cfg['experiment_name'] = 'ws'
+    cfg['training']['warmstart'] = {'include': True, 'optimizer_config': {'name': 'adamw', 'parameters': {'learning_rate': 0.003, 'weight_decay': 0.001}},
+                                    'max_epochs': 6, 'batch_size': 128, 'patience': 3}
+    cfg['training']['sampler'].update(warmup_steps=50, n_samples=20, n_chains=3, desired_energy_var_start=5e-4, desired_energy_var_end=1e-4)
+    (tmp_path / 'cfg.yaml').write_text(yaml.safe_dump(cfg))
+    r = subprocess.run([sys.executable, str(ROOT / 'train.py'), '-c', str(tmp_path / 'cfg.yaml'), '-d', '1'],
+                       capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    exp = tmp_path / 'ws'
+    log = (exp / 'training.log').read_text()
+    assert 'Warmstart Training completed' in log and 'time.warmstart took' in log
+    z = np.load(exp / 'warmstart' / 'params_2.npz')
+    assert np.abs(z['fcn.layer0.bias']).max() > 0                 # module.init starts biases at zero: they were trained
+    assert all(np.isfinite(z[k]).all() for k in z.files)
+    assert sorted(p.name for p in (exp / 'samples' / '1').iterdir()) == ['sample_0.npz', 'sample_10.npz']
+
+
 def test_train_cli_classification_wide_net(tmp_path):
     """The YAML surface on a covertype-shaped problem (7 classes, wide hidden layers -> the layer-wise
     SGEMM path chosen by AUTO, the host-driven tuner because d > 16384)."""

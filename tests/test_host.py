@@ -225,6 +225,21 @@ def test_lenet_spec_config_and_image_loader(tmp_path):
             assert np.abs(v).max() <= 2.0 * math.sqrt(1.0 / fan_in) / 0.87962566103423978 + 1e-6 and v.std() > 0
 
 
+def test_warmstart_earlystop_and_adamw_rules():
+    """earlystop as trainer.py:920-939; one AdamW step as optax computes it."""
+    from mile_amd.warmstart import _Optimizer, earlystop
+    losses = torch.tensor([[5.0, 4.0, 4.1, 4.2, 4.3], [5.0, 4.0, 3.9, 4.2, 3.8], [1.0, 2.0, 3.0, 4.0, 5.0]])
+    assert earlystop(losses, 3).tolist() == [True, False, True]
+    assert earlystop(losses[:, :3], 3).tolist() == [False, False, False]           # not enough history yet
+    th = torch.tensor([[1.0, -2.0]]); g = torch.tensor([[0.5, 0.25]])
+    opt = _Optimizer('adamw', {'learning_rate': 0.1, 'b1': 0.9, 'b2': 0.999, 'eps': 1e-8, 'weight_decay': 0.01}, th)
+    new = opt.step(th, g, torch.tensor([True]))
+    # first step: m_hat = g, v_hat = g^2 -> update = lr * (sign(g) + wd * theta)
+    assert torch.allclose(new, th - 0.1 * (torch.sign(g) + 0.01 * th), atol=1e-6)
+    frozen = opt.step(new, g, torch.tensor([False]))
+    assert torch.equal(frozen, new)
+
+
 def test_train_plan_matches_reference_semantics():
     from mile_amd.sampling import kept_indices
     from mile_amd.trainer import train_plan
