@@ -126,6 +126,12 @@ def main():
     args.ensemble = wl['ensemble'] if args.ensemble is None else args.ensemble
     args.grad_kernel = wl['kernel'] if args.grad_kernel is None else args.grad_kernel
 
+    # stdout carries exactly one JSON line: anything native libraries write to fd 1 (RCCL prints its version
+    # banner there) goes to stderr instead, and the result is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -251,7 +257,7 @@ def main():
             'roofline': roof,
             'cpu_baseline': cpu,
         }
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
