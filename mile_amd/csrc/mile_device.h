@@ -64,9 +64,10 @@ __device__ __forceinline__ f32x4 philox_normal4(uint32_t quad, uint32_t pid, uin
   return z;
 }
 
-// ReLU in ONE instruction: fmaxf(x, 0) costs two (v_max x,x,x to quiet a signalling NaN, then v_max 0,x);
-// v_med3_f32(x, 0, +inf) gives the same values, 0 for a NaN included.
-__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
+// ReLU in ONE instruction: fmaxf(x, 0) and v_med3_f32(x, 0, inf) both get a second one from the compiler (v_max x,x,x to
+// quiet a signalling NaN).  As a signed-integer max the sign bit does the work: negative floats (and -0, and NaNs with the
+// sign bit set) are negative integers -> 0, everything else passes through unchanged.
+__device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 
 __device__ __forceinline__ float act_fwd(int act, float z) {
   if (act == MILE_ACT_RELU) return fmaxf(z, 0.0f);

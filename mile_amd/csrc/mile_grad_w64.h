@@ -27,6 +27,7 @@
 #pragma once
 #include <type_traits>
 
+#include "mile_bf16_frag.h"
 #include "mile_device.h"
 #include "mile_grad_generic.h"
 
@@ -53,12 +54,100 @@ __device__ __forceinline__ void write_image(float *img, const f32x16 (&T)[2], in
     }
 }
 
-template <int NH, int FQ>
+// ---- SPLIT variant: fp32 operands as exact sums of three bf16 terms ------------------------------------------
+// x = x1 + x2 + x3 with x1 = the top 8 significant bits of x, x2 the next 8, x3 the last 8 (each a bf16, the
+// subtractions are exact), so a fp32 product sum a.b becomes the six bf16 MFMA products
+//   a3.b1 + a1.b3 + a2.b2 + a2.b1 + a1.b2 + a1.b1        (accumulated in fp32, small terms first)
+// -- every partial product is exact in fp32; the dropped terms a2.b3, a3.b2, a3.b3 are below 2^-23 of a1.b1, the
+// size of one fp32 rounding.  v_mfma_f32_32x32x16_bf16 does 8x the work of v_mfma_f32_32x32x2_f32 in half the
+// cycles, so the six products cost 3/8 of the fp32 MFMA time.
+__device__ __forceinline__ uint32_t hi16_pair(float x1, float x0) {   // {bf16 bits of x1 : bf16 bits of x0}, truncating
+  return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+}
+__device__ __forceinline__ float trunc_bf16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+
+// One 32x32 T-layout tile (lane = data row j, reg r = feature tfeat(r,h)) -> the B operands of
+// v_mfma_f32_32x32x16_bf16 for its two 16-feature K chunks, in NATURAL feature order (element i of lane (j,h) =
+// feature 16c + 8h + i), three terms each.  The lane halves trade four features per chunk (v_permlane32_swap).
+__device__ __forceinline__ void split3_natk(const f32x16 &T, bf16x8 (&fr)[3][2]) {
+  uint32_t pk[3][8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const float x0 = T[2 * q], x1 = T[2 * q + 1];
+    pk[0][q] = hi16_pair(x1, x0);
+    const float r0 = x0 - trunc_bf16(x0), r1 = x1 - trunc_bf16(x1);
+    pk[1][q] = hi16_pair(r1, r0);
+    pk[2][q] = hi16_pair(r1 - trunc_bf16(r1), r0 - trunc_bf16(r0));
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      // regs 8c..8c+7 = features 16c + {4h..4h+3, 8+4h..8+4h+3}: half 1's first quad <-> half 0's second quad
+      const auto s0 = __builtin_amdgcn_permlane32_swap(pk[t][4 * c], pk[t][4 * c + 2], false, false);
+      const auto s1 = __builtin_amdgcn_permlane32_swap(pk[t][4 * c + 1], pk[t][4 * c + 3], false, false);
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
+      fr[t][c] = __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+// 8 fp32 values -> three bf16x8 terms (weight staging)
+__device__ __forceinline__ void split3_vec(const float (&x)[8], bf16x8 (&o)[3]) {
+  uint32_t pk[3][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float x0 = x[2 * q], x1 = x[2 * q + 1];
+    pk[0][q] = hi16_pair(x1, x0);
+    const float r0 = x0 - trunc_bf16(x0), r1 = x1 - trunc_bf16(x1);
+    pk[1][q] = hi16_pair(r1, r0);
+    pk[2][q] = hi16_pair(r1 - trunc_bf16(r1), r0 - trunc_bf16(r0));
+  }
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const u32x4 v = {pk[t][0], pk[t][1], pk[t][2], pk[t][3]};
+    o[t] = __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+// the six products of one K chunk, ascending in magnitude; a = weight terms, b = activation terms
+#define W64_SPLIT_MFMA6(acc, a, b)            \
+  acc = mfma_bf16((a)[2], (b)[0], acc);       \
+  acc = mfma_bf16((a)[0], (b)[2], acc);       \
+  acc = mfma_bf16((a)[1], (b)[1], acc);       \
+  acc = mfma_bf16((a)[1], (b)[0], acc);       \
+  acc = mfma_bf16((a)[0], (b)[1], acc);       \
+  acc = mfma_bf16((a)[0], (b)[0], acc);
+
+// both output tiles (or, COOP, only tile w): acc[2], a[2][3]
+#define W64_SPLIT_MFMA12(acc, a, b)                                   \
+  if (COOP) {                                                         \
+    W64_SPLIT_MFMA6(acc[w], (a)[w], b)                                \
+  } else {                                                            \
+    acc[0] = mfma_bf16((a)[0][2], (b)[0], acc[0]);                    \
+    acc[1] = mfma_bf16((a)[1][2], (b)[0], acc[1]);                    \
+    acc[0] = mfma_bf16((a)[0][0], (b)[2], acc[0]);                    \
+    acc[1] = mfma_bf16((a)[1][0], (b)[2], acc[1]);                    \
+    acc[0] = mfma_bf16((a)[0][1], (b)[1], acc[0]);                    \
+    acc[1] = mfma_bf16((a)[1][1], (b)[1], acc[1]);                    \
+    acc[0] = mfma_bf16((a)[0][1], (b)[0], acc[0]);                    \
+    acc[1] = mfma_bf16((a)[1][1], (b)[0], acc[1]);                    \
+    acc[0] = mfma_bf16((a)[0][0], (b)[1], acc[0]);                    \
+    acc[1] = mfma_bf16((a)[1][0], (b)[1], acc[1]);                    \
+    acc[0] = mfma_bf16((a)[0][0], (b)[0], acc[0]);                    \
+    acc[1] = mfma_bf16((a)[1][0], (b)[0], acc[1]);                    \
+  }
+
+template <int NH, int FQ, bool SPLIT = false>
 struct W64Layout {
   static constexpr int NW = (NH > 1 ? NH - 1 : 1);
   static constexpr int FP = 8 * FQ;
   static constexpr int WIMG = 0;                                  // [NH-1][64][68]
-  static constexpr int W1IMG = WIMG + (NH - 1) * 64 * W64_RS;     // [FP][68]
+  // SPLIT: instead, bf16 images W^T[out][in] of two layers side by side ([64][128] swizzled, mile_bf16_frag.h),
+  // one per split term: [NSET][3][64 x 256 bytes]
+  static constexpr int NSET = NH / 2;
+  static constexpr int W1IMG = WIMG + (SPLIT ? NSET * 3 * 4096 : (NH - 1) * 64 * W64_RS);   // [FP][68]
   static constexpr int BIAS = W1IMG + FP * W64_RS;                // [NH][64]
   static constexpr int WO = BIAS + NH * 64;                       // [2][64]
   static constexpr int BO = WO + 128;                             // [4]
@@ -74,9 +163,10 @@ struct W64Layout {
   static constexpr int BYTES = TOTAL * 4;
 };
 
-template <int NH, int FQ>
+template <int NH, int FQ, bool SPLIT = false>
 __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p) {
-  using LY = W64Layout<NH, FQ>;
+  using LY = W64Layout<NH, FQ, SPLIT>;
+  static_assert(!SPLIT || NH >= 2, "SPLIT needs a hidden->hidden layer");
   constexpr int FP = LY::FP;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const DevSpec &sp = p.spec;
@@ -93,10 +183,26 @@ __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p) {
   float *img = wv + LY::IMG, *xt = wv + LY::XT, *dout_l = wv + LY::DOUT;
 
   // ---- stage this particle's weights in LDS --------------------------------------
+  char *BIMG = reinterpret_cast<char *>(WIMG);   // SPLIT: term t of image set s at BIMG + (3 s + t) * 16384
   if (!(p.dbg & 2))
   for (int l = 1; l < NH; ++l) {
     const float *W = th + sp.w_off[l];
-    for (int idx = tid; idx < 4096; idx += 256) WIMG[(l - 1) * 64 * W64_RS + (idx >> 6) * W64_RS + (idx & 63)] = W[idx];
+    if constexpr (SPLIT) {
+      // thread task (out, 8 consecutive in): 8 coalesced loads (lanes along out), one 16-byte store per term
+      for (int t = tid; t < 512; t += 256) {
+        const int o = t & 63, ic = t >> 6;
+        float x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = W[(8 * ic + i) * 64 + o];
+        bf16x8 tv[3];
+        split3_vec(x, tv);
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt)
+          *reinterpret_cast<bf16x8 *>(BIMG + (3 * ((l - 1) >> 1) + tt) * 16384 + img_off(o, 8 * ((l - 1) & 1) + ic)) = tv[tt];
+      }
+    } else {
+      for (int idx = tid; idx < 4096; idx += 256) WIMG[(l - 1) * 64 * W64_RS + (idx >> 6) * W64_RS + (idx & 63)] = W[idx];
+    }
   }
   {
     const float *W = th + sp.w_off[0];

@@ -75,6 +75,10 @@ static bool w64_supported(const mile_model_spec &sp) {
   return true;
 }
 
+// the split-bf16 variant replaces the hidden->hidden products, so it needs at least one
+static bool w64x3_supported(const mile_model_spec &sp) { return w64_supported(sp) && sp.n_layers - 1 >= 2; }
+static bool is_w64(int kernel) { return kernel == MILE_GRAD_MFMA_W64 || kernel == MILE_GRAD_MFMA_W64_BF16X3; }
+
 // ---- rocBLAS, resolved at first use: libmile_hip.so has no link-time dependency on it -----------
 typedef int (*rb_create_t)(void **);
 typedef int (*rb_destroy_t)(void *);
@@ -145,7 +149,7 @@ static int generic_R(const DevSpec &ds) {
 }
 
 static int choose_S(const mile_sampler *s, int E, int kernel) {
-  if (kernel == MILE_GRAD_MFMA_W64) {
+  if (is_w64(kernel)) {
     const int NB = s->Npad / 32;
     int S = std::max(1, s->n_cu / std::max(E, 1));
     S = std::min(S, std::max(1, NB / 4));  // keep >= 4 row blocks (one per wave) per workgroup
@@ -392,7 +396,7 @@ int32_t mile_reserve(mile_sampler *s, int32_t E) {
 
 int32_t mile_set_grad_kernel(mile_sampler *s, int32_t which) {
   if (!s) return fail(MILE_ERR_INVALID, "null handle");
-  if (which < MILE_GRAD_AUTO || which > MILE_GRAD_LENET_F32) return fail(MILE_ERR_INVALID, "unknown grad kernel");
+  if (which < MILE_GRAD_AUTO || which > MILE_GRAD_MFMA_W64_BF16X3) return fail(MILE_ERR_INVALID, "unknown grad kernel");
   if ((s->spec.model == MILE_MODEL_LENET) != (which == MILE_GRAD_LENET_F32) && which != MILE_GRAD_AUTO)
     return fail(MILE_ERR_INVALID, "LENET_F32 is the (only) kernel of MILE_MODEL_LENET");
   if (which == MILE_GRAD_GEMM_F32 && !rocblas_load()) return fail(MILE_ERR_HIP, "GEMM_F32 needs librocblas.so, which could not be loaded");
@@ -400,6 +404,8 @@ int32_t mile_set_grad_kernel(mile_sampler *s, int32_t which) {
     return fail(MILE_ERR_INVALID, "MFMA_W128_BF16 needs ReLU regression with 1-3 hidden layers of width 128 and F <= 16");
   if (which == MILE_GRAD_MFMA_W64 && !w64_supported(s->spec))
     return fail(MILE_ERR_INVALID, "MFMA_W64 needs ReLU regression with 1-3 hidden layers of width 64 and F <= 16");
+  if (which == MILE_GRAD_MFMA_W64_BF16X3 && !w64x3_supported(s->spec))
+    return fail(MILE_ERR_INVALID, "MFMA_W64_BF16X3 needs ReLU regression with 2-3 hidden layers of width 64 and F <= 16");
   s->grad_kernel = which;
   return MILE_OK;
 }
@@ -449,16 +455,16 @@ static void launch_update(const UpdParams &u, int E, hipStream_t st) {
   }
 }
 
-template <int NH, int FQ>
+template <int NH, int FQ, bool SPLIT = false>
 static hipError_t launch_w64(const GradParams &gp, int E, hipStream_t st) {
-  using LY = W64Layout<NH, FQ>;
+  using LY = W64Layout<NH, FQ, SPLIT>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_grad_w64<NH, FQ>, hipFuncAttributeMaxDynamicSharedMemorySize, LY::BYTES);
+    hipError_t e = hipFuncSetAttribute((const void *)k_grad_w64<NH, FQ, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LY::BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  k_grad_w64<NH, FQ><<<dim3(gp.S, E), 256, LY::BYTES, st>>>(gp);
+  k_grad_w64<NH, FQ, SPLIT><<<dim3(gp.S, E), 256, LY::BYTES, st>>>(gp);
   return hipGetLastError();
 }
 
@@ -489,8 +495,8 @@ static hipError_t launch_w128b(const GradParams &gp, int E, hipStream_t st) {
   return hipGetLastError();
 }
 
-template <int NH, int FQ>
-static int w64_lds_bytes() { return W64Layout<NH, FQ>::BYTES; }
+template <int NH, int FQ, bool SPLIT = false>
+static int w64_lds_bytes() { return W64Layout<NH, FQ, SPLIT>::BYTES; }
 
 __global__ void k_fill(float *p, float v, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -796,6 +802,14 @@ static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t s
     else if (nh == 2 && fq == 2) e = launch_w64<2, 2>(gp, E, st);
     else if (nh == 3 && fq == 2) e = launch_w64<3, 2>(gp, E, st);
     HIP_TRY(e);
+  } else if (kernel == MILE_GRAD_MFMA_W64_BF16X3) {
+    const int nh = s->spec.n_layers - 1, fq = s->Fp / 8;
+    hipError_t e = hipErrorInvalidValue;
+    if (nh == 2 && fq == 1) e = launch_w64<2, 1, true>(gp, E, st);
+    else if (nh == 3 && fq == 1) e = launch_w64<3, 1, true>(gp, E, st);
+    else if (nh == 2 && fq == 2) e = launch_w64<2, 2, true>(gp, E, st);
+    else if (nh == 3 && fq == 2) e = launch_w64<3, 2, true>(gp, E, st);
+    HIP_TRY(e);
   } else if (kernel == MILE_GRAD_LENET_F32) {
     const int rc = run_lenet(s, theta, E, gp.X, gp.y, s->N, gp.slabs, gp.dp, gp.llpart, nullptr, 0, st);
     if (rc) return rc;
@@ -918,7 +932,7 @@ extern "C" int32_t mile_pointwise_loglik(mile_sampler *s, const float *theta, in
     // wide nets: evaluation stays fp32 whatever the sampling kernel was
     return launch_fwd_gemm(s, theta, S, s->ev_X, s->ev_y, (int)N, out, st);
   }
-  if (kernel == MILE_GRAD_MFMA_W64) {
+  if (is_w64(kernel)) {
     const int NB = Npad / 32;
     pp.SB = std::max(1, std::min(std::max(1, (2 * s->n_cu) / S), std::max(1, NB / 4)));
     const int nh = s->spec.n_layers - 1, fq = Fp / 8;
@@ -957,6 +971,11 @@ int32_t mile_grad_launch_info(const mile_sampler *s, int32_t E, int32_t *grid_x,
     lds = nh == 1 ? (fq == 1 ? w64_lds_bytes<1, 1>() : w64_lds_bytes<1, 2>())
         : nh == 2 ? (fq == 1 ? w64_lds_bytes<2, 1>() : w64_lds_bytes<2, 2>())
                   : (fq == 1 ? w64_lds_bytes<3, 1>() : w64_lds_bytes<3, 2>());
+  } else if (kernel == MILE_GRAD_MFMA_W64_BF16X3) {
+    const int nh = s->spec.n_layers - 1, fq = s->Fp / 8;
+    nm = "k_grad_w64";
+    lds = nh == 2 ? (fq == 1 ? w64_lds_bytes<2, 1, true>() : w64_lds_bytes<2, 2, true>())
+                  : (fq == 1 ? w64_lds_bytes<3, 1, true>() : w64_lds_bytes<3, 2, true>());
   } else if (kernel == MILE_GRAD_LENET_F32) {
     nm = "rocblas_sgemm_strided_batched+k_im2col5/k_col2im5/k_avgpool2";
     lds = 0;

@@ -39,7 +39,7 @@ def _rel(a, b):
     ('regr_relu_8x8_stepO', (8, 8, 2), 5, {}, 'step-O', ('generic',)),
     ('class_tanh_6x4', (6, 4), 7, dict(activation='tanh', task='classification', prior='Laplace', prior_scale=0.5),
      'O-step-O', ('generic',)),
-    ('regr_relu_64x3', (64, 64, 64, 2), 5, {}, 'O-step-O', ('generic', 'mfma_w64')),
+    ('regr_relu_64x3', (64, 64, 64, 2), 5, {}, 'O-step-O', ('generic', 'mfma_w64', 'mfma_w64_bf16x3')),
 ])
 def test_hip_reproduces_golden_vectors(oracle, name, hs, F, kw, refresh, kernels):
     z = np.load(GOLD / f'{name}.npz')
@@ -446,7 +446,7 @@ def test_bf16_kernel_lppd_within_one_percent_of_fp32(oracle):
 
 
 @pytest.mark.parametrize('F,hs,act,task,kernels', [
-    (5, (64, 64, 64, 2), 'relu', 'regr', ('mfma_w64', 'generic')),
+    (5, (64, 64, 64, 2), 'relu', 'regr', ('mfma_w64', 'mfma_w64_bf16x3', 'generic')),
     (5, (64, 2), 'relu', 'regr', ('mfma_w64', 'generic')),
     (9, (24, 17, 2), 'tanh', 'regr', ('generic',)),
     (11, (32, 7), 'sigmoid', 'classification', ('generic', 'gemm_f32')),

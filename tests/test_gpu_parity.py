@@ -26,9 +26,9 @@ def _relerr(a, b):
 
 CASES = [
     # in_features, hidden, activation, task, prior, N, E, kernels
-    (5, (64, 64, 64, 2), 'relu', 'regr', 'Normal', 1052, 16, ('generic', 'mfma_w64')),
-    (5, (64, 64, 64, 2), 'relu', 'regr', 'Normal', 100, 3, ('generic', 'mfma_w64')),
-    (5, (64, 64, 2), 'relu', 'regr', 'Normal', 333, 5, ('generic', 'mfma_w64', 'gemm_f32')),
+    (5, (64, 64, 64, 2), 'relu', 'regr', 'Normal', 1052, 16, ('generic', 'mfma_w64', 'mfma_w64_bf16x3')),
+    (5, (64, 64, 64, 2), 'relu', 'regr', 'Normal', 100, 3, ('generic', 'mfma_w64', 'mfma_w64_bf16x3')),
+    (5, (64, 64, 2), 'relu', 'regr', 'Normal', 333, 5, ('generic', 'mfma_w64', 'mfma_w64_bf16x3', 'gemm_f32')),
     (8, (64, 2), 'relu', 'regr', 'Laplace', 64, 2, ('generic', 'mfma_w64')),
     (5, (16, 16, 2), 'relu', 'regr', 'Normal', 1052, 12, ('generic',)),
     (9, (24, 17, 2), 'tanh', 'regr', 'Normal', 257, 4, ('generic', 'gemm_f32')),
@@ -39,12 +39,12 @@ CASES = [
     (54, (256, 256, 256, 256, 7), 'relu', 'classification', 'Normal', 300, 3, ('gemm_f32', 'generic')),
     # edge cases: one particle, fewer rows than one MFMA block, ragged last block, one hidden layer,
     # more workgroups than row blocks, F at the padding boundary
-    (5, (64, 64, 64, 2), 'relu', 'regr', 'Normal', 2, 1, ('generic', 'mfma_w64')),
-    (5, (64, 64, 64, 2), 'relu', 'regr', 'Normal', 31, 2, ('generic', 'mfma_w64')),
-    (5, (64, 64, 64, 2), 'relu', 'regr', 'Normal', 33, 300, ('generic', 'mfma_w64')),
-    (8, (64, 64, 2), 'relu', 'regr', 'Normal', 1057, 7, ('generic', 'mfma_w64')),
+    (5, (64, 64, 64, 2), 'relu', 'regr', 'Normal', 2, 1, ('generic', 'mfma_w64', 'mfma_w64_bf16x3')),
+    (5, (64, 64, 64, 2), 'relu', 'regr', 'Normal', 31, 2, ('generic', 'mfma_w64', 'mfma_w64_bf16x3')),
+    (5, (64, 64, 64, 2), 'relu', 'regr', 'Normal', 33, 300, ('generic', 'mfma_w64', 'mfma_w64_bf16x3')),
+    (8, (64, 64, 2), 'relu', 'regr', 'Normal', 1057, 7, ('generic', 'mfma_w64', 'mfma_w64_bf16x3')),
     (16, (64, 2), 'relu', 'regr', 'Normal', 129, 2, ('generic', 'mfma_w64')),
-    (9, (64, 64, 2), 'relu', 'regr', 'Normal', 64, 5, ('generic', 'mfma_w64')),
+    (9, (64, 64, 2), 'relu', 'regr', 'Normal', 64, 5, ('generic', 'mfma_w64', 'mfma_w64_bf16x3')),
     (3, (2,), 'relu', 'regr', 'Normal', 40, 3, ('generic',)),
     (6, (5,), 'relu', 'classification', 'Normal', 40, 3, ('generic',)),
 ]
@@ -139,7 +139,7 @@ def test_philox_noise_bits_match_oracle(oracle):
         assert abs(z.mean()) < 0.1 and abs(z.std() - 1) < 0.1
 
 
-@pytest.mark.parametrize('kernel', ['generic', 'mfma_w64'])
+@pytest.mark.parametrize('kernel', ['generic', 'mfma_w64', 'mfma_w64_bf16x3'])
 @pytest.mark.parametrize('refresh', ['O-step-O', 'step-O'])
 def test_steps_match_oracle_explicit_noise(oracle, kernel, refresh):
     ospec = oracle.ModelSpec(5, (64, 64, 64, 2))
