@@ -61,5 +61,14 @@ __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8 a, const bf16x8 b, cons
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+__device__ __forceinline__ float bf16_colsum(const bf16x8 v, float acc) {   // acc + sum of the 8 elements
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bf16x2 pr = {v[2 * i], v[2 * i + 1]}, one = {(bf16)1.0f, (bf16)1.0f};
+    acc = __builtin_amdgcn_fdot2_f32_bf16(pr, one, acc, false);
+  }
+  return acc;
+}
+
 // feature index (within a 32-block) that accumulator register j of lane half h holds
 __device__ __forceinline__ int acc_m(int j, int h) { return (j & 3) + 8 * (j >> 2) + 4 * h; }

@@ -51,15 +51,6 @@ struct W128Layout {
   static constexpr int BYTES = ZERO + 16;
 };
 
-__device__ __forceinline__ float bf16_colsum(const bf16x8 v, float acc) {   // acc + sum of the 8 elements
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const bf16x2 pr = {v[2 * i], v[2 * i + 1]}, one = {(bf16)1.0f, (bf16)1.0f};
-    acc = __builtin_amdgcn_fdot2_f32_bf16(pr, one, acc, false);
-  }
-  return acc;
-}
-
 // Workgroup barrier for LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the global
 // prefetches (X, y of the next tile pair) that are deliberately in flight across it.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

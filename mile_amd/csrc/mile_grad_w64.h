@@ -66,19 +66,23 @@ __device__ __forceinline__ uint32_t hi16_pair(float x1, float x0) {   // {bf16 b
 }
 __device__ __forceinline__ float trunc_bf16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
 
-// One 32x32 T-layout tile (lane = data row j, reg r = feature tfeat(r,h)) -> the B operands of
-// v_mfma_f32_32x32x16_bf16 for its two 16-feature K chunks, in NATURAL feature order (element i of lane (j,h) =
-// feature 16c + 8h + i), three terms each.  The lane halves trade four features per chunk (v_permlane32_swap).
-__device__ __forceinline__ void split3_natk(const f32x16 &T, bf16x8 (&fr)[3][2]) {
-  uint32_t pk[3][8];
+// One 32x32 T-layout tile (lane = data row j, reg r = feature tfeat(r,h)) -> packed bf16 pairs of its three terms:
+// pk[t][q] = {term t of reg 2q+1 : term t of reg 2q}.
+__device__ __forceinline__ void split3_pk(const f32x16 &T, uint32_t (&pk)[3][8]) {
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
-    const float x0 = T[2 * q], x1 = T[2 * q + 1];
-    pk[0][q] = hi16_pair(x1, x0);
-    const float r0 = x0 - trunc_bf16(x0), r1 = x1 - trunc_bf16(x1);
-    pk[1][q] = hi16_pair(r1, r0);
-    pk[2][q] = hi16_pair(r1 - trunc_bf16(r1), r0 - trunc_bf16(r0));
+    const f32x2 x = {T[2 * q], T[2 * q + 1]};
+    pk[0][q] = hi16_pair(x[1], x[0]);
+    const f32x2 r = x - f32x2{trunc_bf16(x[0]), trunc_bf16(x[1])};
+    pk[1][q] = hi16_pair(r[1], r[0]);
+    const f32x2 s = r - f32x2{trunc_bf16(r[0]), trunc_bf16(r[1])};
+    pk[2][q] = hi16_pair(s[1], s[0]);
   }
+}
+
+// -> the B operands of v_mfma_f32_32x32x16_bf16 for the tile's two 16-feature K chunks, in NATURAL feature order
+// (element i of lane (j,h) = feature 16c + 8h + i).  The lane halves trade four features per chunk (v_permlane32_swap).
+__device__ __forceinline__ void natk_from_pk(const uint32_t (&pk)[3][8], bf16x8 (&fr)[3][2]) {
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -90,6 +94,30 @@ __device__ __forceinline__ void split3_natk(const f32x16 &T, bf16x8 (&fr)[3][2])
       const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
       fr[t][c] = __builtin_bit_cast(bf16x8, v);
     }
+}
+
+__device__ __forceinline__ void split3_natk(const f32x16 &T, bf16x8 (&fr)[3][2]) {
+  uint32_t pk[3][8];
+  split3_pk(T, pk);
+  natk_from_pk(pk, fr);
+}
+
+// The wave's private transposition buffer in the SPLIT variant: two swizzled [32 rows][128 columns] bf16 images
+// (mile_bf16_frag.h); term 0 of a 64-feature row lives in columns 0..63 of image 0, term 1 in columns 64..127 of image 0,
+// term 2 in columns 0..63 of image 1.  Stores tile kb (features 32kb..32kb+31) of all three terms: img[row j][feature].
+__device__ __forceinline__ void store_terms(char *si, int kb, const uint32_t (&pk)[3][8], int j, int h) {
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 v = {pk[t][2 * g], pk[t][2 * g + 1]};
+      *reinterpret_cast<u32x2 *>(si + (t == 2 ? 8192 : 0) + img_off(j, (t == 1 ? 8 : 0) + 4 * kb + g) + 8 * h) = v;
+    }
+}
+// transposed fragment of term t: element i of lane (r,h) = term t of img[row 16c + 8h + i][feature 32fb + r]
+__device__ __forceinline__ bf16x8 terms_tr_frag(const char *si, int t, int c, int fb, int lane) {
+  return tr_frag(si + (t == 2 ? 8192 : 0), 16 * c, (t == 1 ? 64 : 0) + 32 * fb, lane);
 }
 
 // 8 fp32 values -> three bf16x8 terms (weight staging)
@@ -111,33 +139,19 @@ __device__ __forceinline__ void split3_vec(const float (&x)[8], bf16x8 (&o)[3]) 
   }
 }
 
-// the six products of one K chunk, ascending in magnitude; a = weight terms, b = activation terms
-#define W64_SPLIT_MFMA6(acc, a, b)            \
-  acc = mfma_bf16((a)[2], (b)[0], acc);       \
-  acc = mfma_bf16((a)[0], (b)[2], acc);       \
-  acc = mfma_bf16((a)[1], (b)[1], acc);       \
-  acc = mfma_bf16((a)[1], (b)[0], acc);       \
-  acc = mfma_bf16((a)[0], (b)[1], acc);       \
-  acc = mfma_bf16((a)[0], (b)[0], acc);
-
-// both output tiles (or, COOP, only tile w): acc[2], a[2][3]
-#define W64_SPLIT_MFMA12(acc, a, b)                                   \
-  if (COOP) {                                                         \
-    W64_SPLIT_MFMA6(acc[w], (a)[w], b)                                \
-  } else {                                                            \
-    acc[0] = mfma_bf16((a)[0][2], (b)[0], acc[0]);                    \
-    acc[1] = mfma_bf16((a)[1][2], (b)[0], acc[1]);                    \
-    acc[0] = mfma_bf16((a)[0][0], (b)[2], acc[0]);                    \
-    acc[1] = mfma_bf16((a)[1][0], (b)[2], acc[1]);                    \
-    acc[0] = mfma_bf16((a)[0][1], (b)[1], acc[0]);                    \
-    acc[1] = mfma_bf16((a)[1][1], (b)[1], acc[1]);                    \
-    acc[0] = mfma_bf16((a)[0][1], (b)[0], acc[0]);                    \
-    acc[1] = mfma_bf16((a)[1][1], (b)[0], acc[1]);                    \
-    acc[0] = mfma_bf16((a)[0][0], (b)[1], acc[0]);                    \
-    acc[1] = mfma_bf16((a)[1][0], (b)[1], acc[1]);                    \
-    acc[0] = mfma_bf16((a)[0][0], (b)[0], acc[0]);                    \
-    acc[1] = mfma_bf16((a)[1][0], (b)[0], acc[1]);                    \
-  }
+// The six products of one K chunk for both output tiles (COOP: only tile w), streamed operand = the weight / image
+// fragments a[tile][term] (single-buffered), fixed operand b[term].  The fragments of the NEXT chunk are requested as soon
+// as the last MFMA that reads the register has been issued: term 2 after the first pair, term 0 after four pairs, term 1
+// at the end -- each at least ~190 cycles before its first use in the next group.  W64_SB lets VALU / SALU work (the
+// split of the next tile) float across but pins LDS reads and MFMAs.
+#define W64_SB __builtin_amdgcn_sched_barrier(0x6);
+#define W64_MF2(acc, a, ta, b, tb)                                                   \
+  if (!COOP || w == 0) acc[0] = mfma_bf16((a)[0][ta], (b)[tb], acc[0]);              \
+  if (!COOP || w == 1) acc[1] = mfma_bf16((a)[1][ta], (b)[tb], acc[1]);
+#define W64_PIPE_A(acc, a, b, LOAD)                                                   \
+  W64_MF2(acc, a, 2, b, 0) W64_SB LOAD(2) W64_SB                                      \
+  W64_MF2(acc, a, 0, b, 2) W64_MF2(acc, a, 0, b, 1) W64_MF2(acc, a, 0, b, 0) W64_SB LOAD(0) W64_SB \
+  W64_MF2(acc, a, 1, b, 1) W64_MF2(acc, a, 1, b, 0) W64_SB LOAD(1) W64_SB
 
 template <int NH, int FQ, bool SPLIT = false>
 struct W64Layout {
@@ -147,13 +161,16 @@ struct W64Layout {
   // SPLIT: instead, bf16 images W^T[out][in] of two layers side by side ([64][128] swizzled, mile_bf16_frag.h),
   // one per split term: [NSET][3][64 x 256 bytes]
   static constexpr int NSET = NH / 2;
+  // the row-contracting dW products run on bf16 terms as well where the registers allow it: with three hidden layers
+  // (128 dW accumulators + 96 activation registers live) the extra fragments spill and the fp32 MFMA form is faster
+  static constexpr bool SPLIT_DW = SPLIT && NH <= 2;
   static constexpr int W1IMG = WIMG + (SPLIT ? NSET * 3 * 4096 : (NH - 1) * 64 * W64_RS);   // [FP][68]
   static constexpr int BIAS = W1IMG + FP * W64_RS;                // [NH][64]
   static constexpr int WO = BIAS + NH * 64;                       // [2][64]
   static constexpr int BO = WO + 128;                             // [4]
   static constexpr int WAVE0 = BO + 4;
-  static constexpr int IMG = 0;                                   // per wave: [32][68]
-  static constexpr int XT = IMG + 32 * W64_RS;                    // [32][FP]
+  static constexpr int IMG = 0;                                   // per wave: [32][68]; SPLIT_DW: aliased by two bf16 images, 16 KB
+  static constexpr int XT = IMG + (SPLIT_DW ? 4096 : 32 * W64_RS);   // [32][FP]
   static constexpr int DOUT = XT + 32 * FP;                       // [32][2]
   static constexpr int WAVE_SZ = DOUT + 64;
   static constexpr int XB = WAVE0 + 4 * WAVE_SZ;                  // [2 pairs][2][2][16][64] tile exchange (COOP)

@@ -1,5 +1,5 @@
 """fp32-MFMA vs split-bf16 (bf16x3, six products) width-64 grad kernel: time and error of BOTH against the fp64 oracle.
-Dev tool.  usage: python tools/split_check.py [N] [E] [nh]"""
+Dev tool.  usage: python tools/split_check.py [N] [E] [nh] [F]"""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -11,7 +11,7 @@ from oracle import mclmc_oracle as O
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1052
 E = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 nh = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-F = 5
+F = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 hs = (64,) * nh + (2,)
 spec = ModelSpec(F, hs)
 so = O.ModelSpec(in_features=F, hidden_structure=hs)
