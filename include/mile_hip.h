@@ -57,8 +57,9 @@ typedef enum mile_task { MILE_TASK_REGRESSION = 0, MILE_TASK_CLASSIFICATION = 1 
 typedef enum mile_prior { MILE_PRIOR_NORMAL = 0, MILE_PRIOR_LAPLACE = 1 } mile_prior;
 /* Placement of the partial momentum refresh inside one kernel step. */
 typedef enum mile_refresh { MILE_REFRESH_O_STEP_O = 0, MILE_REFRESH_STEP_O = 1 } mile_refresh;
-/* Which grad-log-posterior kernel to use.  AUTO picks the fastest fp32 kernel that supports the spec;
- * the bf16-operand kernel (fp32 accumulate, fp32 parameters) is only ever selected explicitly. */
+/* Which grad-log-posterior kernel to use.  AUTO picks the fastest fp32-accurate kernel that supports the spec
+ * (MFMA_W64_BF16X3 reproduces fp32 products exactly from three-term bf16 splits and counts as one); the
+ * bf16-operand kernel MFMA_W128_BF16 (operands ROUNDED to bf16, fp32 accumulate) is only ever selected explicitly. */
 typedef enum mile_grad_kernel {
   MILE_GRAD_AUTO = 0,
   MILE_GRAD_GENERIC = 1,          /* any FCN, fp32 VALU */

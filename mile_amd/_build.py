@@ -36,8 +36,11 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     """hipcc --offload-arch=gfx950 -shared -fPIC -> mile_amd/libmile_hip.so."""
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [_hipcc(), '-O3', '--offload-arch=gfx950', '-std=c++17', '-shared', '-fPIC',
-           '-o', str(LIB_PATH)] + [str(CSRC / f) for f in SOURCES] + ['-ldl']
+    extra = os.environ.get('MILE_HIPCC_FLAGS', '').split()          # dev: extra compiler flags for experiments
+    # -amdgpu-mfma-vgpr-form: MFMA results that the VALU consumes next land in VGPRs instead of AGPRs (fewer
+    # v_accvgpr moves and spills in the register-bound grad kernels; measured +0.5 % w64, +2 % w128b)
+    cmd = [_hipcc(), '-O3', '--offload-arch=gfx950', '-std=c++17', '-shared', '-fPIC', '-mllvm', '-amdgpu-mfma-vgpr-form'] + extra + \
+          ['-o', str(LIB_PATH)] + [str(CSRC / f) for f in SOURCES] + ['-ldl']
     if verbose:
         print(' '.join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)

@@ -134,6 +134,7 @@ static bool w128b_supported(const mile_model_spec &sp) {
 static int resolved_kernel(const mile_sampler *s) {
   if (s->spec.model == MILE_MODEL_LENET) return MILE_GRAD_LENET_F32;
   if (s->grad_kernel == MILE_GRAD_AUTO) {
+    if (w64x3_supported(s->spec)) return MILE_GRAD_MFMA_W64_BF16X3;   // fp32-faithful and never slower than MFMA_W64
     if (w64_supported(s->spec)) return MILE_GRAD_MFMA_W64;
     return gemm_preferred(s->spec) && rocblas_load() ? MILE_GRAD_GEMM_F32 : MILE_GRAD_GENERIC;
   }
