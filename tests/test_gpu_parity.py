@@ -67,6 +67,30 @@ def test_logpost_grad_matches_oracle(oracle, F, hs, act, task, prior, N, E, kern
         assert _relerr(g.cpu().numpy(), g_ref) < 2e-5, k
 
 
+@pytest.mark.parametrize('F,hs,N,E', [(5, (64, 64, 64, 2), 1052, 32), (12, (64, 64, 2), 777, 9), (5, (64, 64, 2), 64, 300)])
+def test_split_bf16_w64_kernel_is_fp32_faithful(oracle, F, hs, N, E):
+    """mfma_w64_bf16x3 (what AUTO picks for 2-3 hidden layers of width 64) forms each fp32 product exactly from
+    three-term bf16 splits and drops only terms below 2^-23 of the leading one, so its error against the fp64 oracle
+    must be fp32-rounding-sized: worst particle and ensemble mean no worse than 2x those of the fp32-MFMA kernel (+1e-7
+    of the largest entry), and an order of magnitude inside the 2e-5 tolerance the other tests use."""
+    ospec = oracle.ModelSpec(F, hs)
+    prob = oracle.synthetic_problem(ospec, N, E, seed=21)
+    lp_ref, g_ref = oracle.logpost_and_grad(ospec, prob['theta0'].astype(np.float64), prob['X'], prob['y'])
+    scale = np.abs(g_ref).max(axis=1, keepdims=True)
+    err = {}
+    for k in ('mfma_w64', 'mfma_w64_bf16x3'):
+        eng = _engine(oracle, ospec, prob, k)
+        assert eng.grad_kernel == k
+        lp, g = eng.logpost_grad(torch.from_numpy(prob['theta0']))
+        torch.cuda.synchronize()
+        err[k] = (np.abs(g.cpu().numpy().astype(np.float64) - g_ref) / scale).max(axis=1)     # per particle
+        assert _relerr(lp.cpu().numpy(), lp_ref) < 1e-6, k
+    assert err['mfma_w64_bf16x3'].max() <= 2.0 * err['mfma_w64'].max() + 1e-7, (err['mfma_w64_bf16x3'].max(), err['mfma_w64'].max())
+    assert err['mfma_w64_bf16x3'].mean() <= 2.0 * err['mfma_w64'].mean() + 1e-8, (err['mfma_w64_bf16x3'].mean(), err['mfma_w64'].mean())
+    assert err['mfma_w64_bf16x3'].max() < 2e-6
+    assert _engine(oracle, ospec, prob, 'auto').grad_kernel == 'mfma_w64_bf16x3'
+
+
 BF16_CASES = [
     # in_features, hidden, N, E   (ReLU regression, width 128: what k_grad_w128b supports)
     (9, (128, 128, 128, 2), 1000, 5),
