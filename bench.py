@@ -228,12 +228,11 @@ def main():
         if eng.grad_kernel == 'mfma_w64_bf16x3':
             # `peak` stays the fp32 MFMA peak (the arithmetic is fp32: exact products of 3-term bf16 splits, fp32
             # accumulation).  The kernel's own MFMA-pipe floor is lower than an all-fp32 kernel's: hidden forward /
-            # dH (and, <= 2 hidden layers, dW) tiles cost 6 bf16 MFMAs x 32 clk per 16-deep chunk instead of
-            # 8 fp32 MFMAs x 64 clk.  `frac_of_mix_bound` prices `achieved` against that instruction mix.
+            # dH / dW tiles cost 6 bf16 MFMAs x 32 clk per 16-deep chunk instead of 8 fp32 MFMAs x 64 clk (only
+            # the first layer stays on the fp32 MFMA).  `frac_of_mix_bound` prices `achieved` against that mix.
             nh, fq = len(spec.hidden_structure) - 1, (spec.in_features + 7) // 8
-            split_dw = nh <= 2
             clk_fp32 = (8 * fq + 192 * (nh - 1)) * 64
-            clk_mix = (8 * fq + (0 if split_dw else 64 * (nh - 1))) * 64 + (nh - 1) * (96 + (48 if split_dw else 0)) * 32
+            clk_mix = 8 * fq * 64 + (nh - 1) * 144 * 32
             roof['mix'] = 'hidden-layer products as 6 bf16 MFMA products of exact 3-term bf16 splits (fp32-faithful)'
             roof['peak_mix_bound'] = round(peak * clk_fp32 / clk_mix, 1)
             roof['frac_of_mix_bound'] = round(achieved / (peak * clk_fp32 / clk_mix), 4)

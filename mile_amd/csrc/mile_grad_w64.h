@@ -161,9 +161,13 @@ struct W64Layout {
   // SPLIT: instead, bf16 images W^T[out][in] of two layers side by side ([64][128] swizzled, mile_bf16_frag.h),
   // one per split term: [NSET][3][64 x 256 bytes]
   static constexpr int NSET = NH / 2;
-  // the row-contracting dW products run on bf16 terms as well where the registers allow it: with three hidden layers
-  // (128 dW accumulators + 96 activation registers live) the extra fragments spill and the fp32 MFMA form is faster
-  static constexpr bool SPLIT_DW = SPLIT && NH <= 2;
+  // The row-contracting dW products run on bf16 terms as well (SPLIT_DW; split_dw(l) selects it per layer).  With three
+  // hidden layers that only fits the register file because (a) the swizzled fragment addresses are re-derived per layer from
+  // an opaque copy of the lane index instead of living in ~30 hoisted registers, and (b) the first layer's activations wait
+  // in LDS between forward and backward (STASH: each wave's quarter of the tile-exchange buffer, idle in the main loop).
+  static constexpr bool SPLIT_DW = SPLIT;
+  __host__ __device__ static constexpr bool split_dw(int l) { return SPLIT; }
+  static constexpr bool STASH = SPLIT && NH >= 3;
   static constexpr int W1IMG = WIMG + (SPLIT ? NSET * 3 * 4096 : (NH - 1) * 64 * W64_RS);   // [FP][68]
   static constexpr int BIAS = W1IMG + FP * W64_RS;                // [NH][64]
   static constexpr int WO = BIAS + NH * 64;                       // [2][64]
@@ -301,6 +305,8 @@ __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p) {
 #undef W64_PREF
   }
 #define W64_PREF 0
+  // STASH: a wave of a pair must not start exchanging tiles through the buffer its partner still keeps activations in
+  if constexpr (LY::STASH) __syncthreads();
   if (rem == 3) {               // three leftovers: one more independent round
     if (wave < 3) {
       const int row0 = (b0 + 4 * nfull + wave) * 32;
