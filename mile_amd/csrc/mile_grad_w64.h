@@ -24,6 +24,11 @@
 //
 // Work per 32-row block and wave: 392 v_mfma_f32_32x32x2_f32 (8 + 2*64 forward,
 // 4*64 backward) = 1.606 MFLOP of the 1.638 MFLOP the algorithm needs for 32 rows.
+//
+// SPLIT = true (mfma_w64_bf16x3, what AUTO selects for 2-3 hidden layers): the same kernel with every
+// hidden->hidden product (forward, dH, dW) as six v_mfma_f32_32x32x16_bf16 products of exact three-term bf16
+// splits of the fp32 operands -- fp32-faithful, 8 + 288 MFMAs = 9.7k instead of 25.1k matrix-pipe cycles per block.
+// See the comments at split3_pk / W64_PIPE_A / W64Layout below and DESIGN.md section 3.1b.
 #pragma once
 #include <type_traits>
 
