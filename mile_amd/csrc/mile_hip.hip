@@ -424,11 +424,15 @@ static int ptr_align(const void *q) {   // alignment in floats (4, 2 or 1) of a 
 
 template <int AL, bool SDC>
 static void launch_update_al(const UpdParams &u, int E, int nk, hipStream_t st) {
+  // fewest waves that still leave <= nk quads per thread: padded lanes are wasted VALU time in a kernel that only fills
+  // half the chip (d = 8834: 2208 quads, nk = 3 -> 768 threads instead of 1024)
+  const int nqf = u.d >> 2;
+  const int nt = std::min(UPD_NT, ((nqf + nk - 1) / nk + 63) / 64 * 64);
   switch (nk) {
-    case 1: k_update_fast<1, AL, SDC><<<E, UPD_NT, 0, st>>>(u); break;
-    case 2: k_update_fast<2, AL, SDC><<<E, UPD_NT, 0, st>>>(u); break;
-    case 3: k_update_fast<3, AL, SDC><<<E, UPD_NT, 0, st>>>(u); break;
-    default: k_update_fast<4, AL, SDC><<<E, UPD_NT, 0, st>>>(u); break;
+    case 1: k_update_fast<1, AL, SDC><<<E, nt, 0, st>>>(u); break;
+    case 2: k_update_fast<2, AL, SDC><<<E, nt, 0, st>>>(u); break;
+    case 3: k_update_fast<3, AL, SDC><<<E, nt, 0, st>>>(u); break;
+    default: k_update_fast<4, AL, SDC><<<E, nt, 0, st>>>(u); break;
   }
 }
 

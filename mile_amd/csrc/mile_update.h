@@ -324,7 +324,9 @@ __device__ __forceinline__ void st4(float *q, const f32x4 v) {
 template <int NK, int AL, bool SDC>
 __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
   __shared__ float red[UPD_NW][UPD_NSUM + 1];
-  const int tid = threadIdx.x, e = blockIdx.x, d = p.d;
+  // launched with the fewest waves that still give NK quads per thread (nt = blockDim.x <= UPD_NT, a multiple of 64): the
+  // kernel is VALU-bound on half the chip (E workgroups), so idle padded lanes cost real time (d = 8834: 768 threads, not 1024)
+  const int tid = threadIdx.x, e = blockIdx.x, d = p.d, nt = blockDim.x;
   const size_t base = (size_t)e * d;
   const int nqf = d >> 2;            // full quads
   const int ntail = d & 3;           // leftover elements, handled by threads 0..ntail-1
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
   // ---- pass 1: loads -----------------------------------------------------------------
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
-    const int q = tid + k * UPD_NT;
+    const int q = tid + k * nt;
     const bool valid = q < nqf;
     const size_t o = base + 4 * (size_t)(valid ? q : 0);
     cx[k] = ld4<AL>(xin + o);
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
   for (int k = 0; k < UPD_NSUM; ++k) sm[k] = 0.0f;
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
-    const int q = tid + k * UPD_NT;
+    const int q = tid + k * nt;
     if (useA && !p.zA) ca[k] = philox_normal4(q, pid, p.stepA, p.stageA, p.seed);
     if (useB && !p.zB) cb[k] = philox_normal4(q, pid, p.stepB, p.stageB, p.seed);
     const float mk = q < nqf ? 1.0f : 0.0f;
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
     float t = 0.0f;
     const int kk = tid < UPD_NSUM ? tid : 0;
 #pragma unroll
-    for (int w = 0; w < UPD_NW; ++w) t += red[w][kk];
+    for (int w = 0; w < (nt >> 6); ++w) t += red[w][kk];
 #pragma unroll
     for (int k = 0; k < UPD_NSUM; ++k) S[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), k));
   }
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
   const bool t_ok = bc[5] != 0.0f;
   const float t_Wold = bc[6], t_wgt = bc[7];
   if (tune && !t_ok) {   // handle_nans: this chain keeps its previous state (rare, workgroup-uniform)
-    for (int i = tid; i < d; i += UPD_NT) {
+    for (int i = tid; i < d; i += nt) {
       p.x[base + i] = p.bk_x[base + i];
       p.u[base + i] = p.bk_u[base + i];
       p.g[base + i] = p.bk_g[base + i];
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
   const float t_den = 1.0f / (t_Wold + t_wgt);              // zero_prevention = mask = 0 here
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
-    const int q = tid + k * UPD_NT;
+    const int q = tid + k * nt;
     if (q < nqf) {
       const size_t o = base + 4 * (size_t)q;
       if (t_acc) {
