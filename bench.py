@@ -6,10 +6,19 @@ N=1052, F=5; FCN hidden_structure [64,64,64,2] (ReLU, Gaussian head, StandardNor
 prior), d=8834; E=128 particles PER GPU (weak scaling); one "step" = one full MCLMC
 kernel step (O.B.A.B.A.B.O, two full-batch gradients) of every particle on the rank;
 counter-RNG noise; position kept every 10th step (stock n_thinning) into an HBM buffer;
-for N>1 the kept samples of each chunk are all-gathered over RCCL asynchronously
-(sample collection), overlapped with the next chunk's steps.
+for N>1 the kept samples of each chunk are all-gathered over RCCL (sample collection).
+
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts its own N ranks
+(child processes, one per GPU; the parent never touches the GPU) and relays rank 0's line.
+Under `python -m torch.distributed.run ... bench.py --gpus N` it is one of the N ranks.
+
+Timing: W untimed warm-up steps, a clock warm-up, then the timed region -- EXACTLY K steps
+between barrier + synchronize on both sides, max over ranks -- is repeated (>= 5 times,
+about a second in total) and the MEDIAN repetition is reported, so a short region (the
+driver passes --steps 20: 3 ms) is not dominated by clock ramp and first-launch effects.
 
 Prints ONE JSON line on rank 0.  `value` = particles x steps / wall seconds over all ranks.
+The default run adds BASELINE configs[2] (B3) as a bounded secondary leg inside the same line.
 """
 from __future__ import annotations
 
@@ -17,6 +26,9 @@ import argparse
 import json
 import math
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -25,11 +37,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 WORKLOAD = 'B2'
-E_PER_GPU = 128
 N_THINNING = 10
 CHUNK = 50                       # steps per sample-collection chunk
 PEAK_FP32_MFMA_TFLOPS = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
@@ -38,10 +46,11 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 (same guide; never the 2:1-sparsit
 # The driver's bench line is B2 (the default).  --workload B3 reports BASELINE configs[2] in the same format.
 WORKLOADS = {
     'B2': dict(ensemble=128, kernel='auto', dtype='f32', peak=PEAK_FP32_MFMA_TFLOPS, steps=400, warmup=50, cpu_particles=None,
+               cpu_seconds=15.0,
                text='B2: airfoil-shaped N=1052 F=5, FCN hidden_structure [64,64,64,2] relu, Gaussian head, '
                     'StandardNormal prior, d=8834'),
     'B3': dict(ensemble=512, kernel='mfma_w128_bf16', dtype='bf16', peak=PEAK_BF16_MFMA_TFLOPS, steps=40, warmup=5,
-               cpu_particles=16,
+               cpu_particles=16, cpu_seconds=8.0,
                text='B3: protein-shaped N=36000 F=9, FCN hidden_structure [128,128,128,2] relu, Gaussian head, '
                     'StandardNormal prior, d=34562; bf16 matrix operands, fp32 accumulation/parameters/integrator'),
 }
@@ -62,6 +71,7 @@ def cpu_baseline(spec_o, prob, oracle, seconds_target=15.0):
     """The oracle's C/OpenMP restatement (oracle/cpu_mclmc.c: fp32, one particle per core, the shape
     of the reference's own CPU run) on the host cores, on a bounded sample of the same workload: all E
     particles, a few steps.  Falls back to the NumPy oracle if the C library cannot be built."""
+    import numpy as np
     dt = np.float32
     E, d = prob['theta0'].shape
     rng = np.random.default_rng(0)
@@ -108,118 +118,155 @@ def cpu_baseline(spec_o, prob, oracle, seconds_target=15.0):
                       f'{el:.1f} s' + note}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--workload', default=WORKLOAD, choices=sorted(WORKLOADS))
-    ap.add_argument('--steps', type=int, default=None)
-    ap.add_argument('--warmup', type=int, default=None)
-    ap.add_argument('--ensemble', type=int, default=None, help='particles per GPU')
-    ap.add_argument('--grad-kernel', default=None)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--force-dist', action='store_true', help='init the process group even for 1 rank (rehearsal)')
-    args = ap.parse_args()
-    wl = WORKLOADS[args.workload]
-    args.steps = wl['steps'] if args.steps is None else args.steps
-    args.warmup = wl['warmup'] if args.warmup is None else args.warmup
-    args.ensemble = wl['ensemble'] if args.ensemble is None else args.ensemble
-    args.grad_kernel = wl['kernel'] if args.grad_kernel is None else args.grad_kernel
+# ----------------------------------------------------------------------------------------------
+# N > 1 without a launcher: the parent starts one child per GPU and never initialises the GPU itself
+# ----------------------------------------------------------------------------------------------
+def spawn_ranks(n: int, argv: list[str]) -> int:
+    with socket.socket() as s:                      # a free rendezvous port on the loopback interface
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), MILE_BENCH_CHILD='1')
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    print(f'bench.py: started {n} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}', file=sys.stderr)
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:               # one rank failed: the others would wait in a collective forever
+                rc = code
+                print(f'bench.py: rank {r} exited with code {code}; stopping the other ranks', file=sys.stderr)
+                for q in sorted(alive):
+                    procs[q].terminate()            # exact pids of our own children
+        time.sleep(0.05)
+    out = procs[0].stdout.read().decode() if procs[0].stdout else ''
+    if rc == 0:
+        lines = [ln for ln in out.splitlines() if ln.startswith('{')]
+        if len(lines) != 1:
+            print(f'bench.py: expected one JSON line from rank 0, got {len(lines)}', file=sys.stderr)
+            return 1
+        sys.stdout.write(lines[0] + '\n')
+        sys.stdout.flush()
+    return rc if rc else 0
 
-    # stdout carries exactly one JSON line: anything native libraries write to fd 1 (RCCL prints its version
-    # banner there) goes to stderr instead, and the result is written to the saved descriptor at the end
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
 
-    rank = int(os.environ.get('RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f'cuda:{local_rank}')
-    dist = None
-    if world > 1 or args.force_dist:
-        import torch.distributed as dist_
-        dist = dist_
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+class Leg:
+    """One workload on this rank's GPU: engine, state and the chunked stepping loop."""
 
-    # the oracle is imported here ONLY as workload generator (synthetic_problem) and for the
-    # cpu_baseline leg; the timed path below never touches it
-    from oracle import mclmc_oracle as oracle
-    from mile_amd import ModelSpec
-    from mile_amd.engine import Engine
+    def __init__(self, name, args, dist, rank, world, dev, gather_cpu):
+        import torch
+        from oracle import mclmc_oracle as oracle      # workload generator + cpu_baseline leg only; never in the timed path
+        from mile_amd import ModelSpec
+        from mile_amd.engine import Engine
+        self.torch, self.oracle, self.dist, self.rank, self.world, self.dev = torch, oracle, dist, rank, world, dev
+        self.name, self.wl = name, WORKLOADS[name]
+        self.gather_cpu, self.async_gather = gather_cpu, args.async_gather
+        self.spec_o, self.N, _ = oracle.config_spec(name)
+        self.E = E = args.ensemble if (args.ensemble and name == args.workload) else self.wl['ensemble']
+        kernel = args.grad_kernel if (args.grad_kernel and name == args.workload) else self.wl['kernel']
+        self.prob = prob = oracle.synthetic_problem(self.spec_o, self.N, E * world, seed=0)
+        lo, hi = rank * E, (rank + 1) * E
+        self.spec = ModelSpec(self.spec_o.in_features, self.spec_o.hidden_structure, activation='relu', task='regr',
+                              prior='StandardNormal')
+        self.eng = Engine(self.spec, torch.from_numpy(prob['X']), torch.from_numpy(prob['y']), device=dev, grad_kernel=kernel)
+        self.ids = torch.arange(lo, hi, dtype=torch.int32, device=dev)
+        self.eps = torch.from_numpy(prob['eps'][lo:hi]).to(dev)
+        self.L = torch.from_numpy(prob['L'][lo:hi]).to(dev)
+        self.state = self.eng.init(torch.from_numpy(prob['theta0'][lo:hi]), seed=1234, particle_ids=self.ids)
+        self.offset = 0
 
-    spec_o, N, _ = oracle.config_spec(args.workload)
-    E = args.ensemble
-    prob = oracle.synthetic_problem(spec_o, N, E * world, seed=0)
-    lo, hi = rank * E, (rank + 1) * E
-    spec = ModelSpec(spec_o.in_features, spec_o.hidden_structure, activation='relu', task='regr',
-                     prior='StandardNormal')
-    eng = Engine(spec, torch.from_numpy(prob['X']), torch.from_numpy(prob['y']), device=dev,
-                 grad_kernel=args.grad_kernel)
-    ids = torch.arange(lo, hi, dtype=torch.int32, device=dev)
-    eps = torch.from_numpy(prob['eps'][lo:hi]).to(dev)
-    L = torch.from_numpy(prob['L'][lo:hi]).to(dev)
-    state = eng.init(torch.from_numpy(prob['theta0'][lo:hi]), seed=1234, particle_ids=ids)
-
-    def run(n_steps, offset, state, collect):
-        """n_steps steps in chunks; returns (state, list of pending all-gathers)."""
+    def run(self, n_steps, state=None, collect=True):
+        """n_steps steps in chunks of CHUNK; kept samples of every chunk are all-gathered (N > 1)."""
+        torch, dist = self.torch, self.dist
+        own = state is None
+        state = self.state if own else state
         pending, done = [], 0
         while done < n_steps:
             c = min(CHUNK, n_steps - done)
-            state, _, samples = eng.step(state, eps, L, n_steps=c, seed=1234, step_offset=offset + done,
-                                         n_thinning=N_THINNING, particle_ids=ids, want_info=False, inplace=True)
+            state, _, samples = self.eng.step(state, self.eps, self.L, n_steps=c, seed=1234, step_offset=self.offset + done,
+                                              n_thinning=N_THINNING, particle_ids=self.ids, want_info=False, inplace=True)
             if collect and dist is not None and samples is not None:
-                out = torch.empty((world * samples.shape[0],) + tuple(samples.shape[1:]), dtype=samples.dtype, device=dev)
-                pending.append((dist.all_gather_into_tensor(out, samples, async_op=True), out, samples))
+                if self.gather_cpu:                 # single-device rehearsal under gloo: stage through the host
+                    loc = samples.cpu()
+                    out = torch.empty((self.world * loc.shape[0],) + tuple(loc.shape[1:]), dtype=loc.dtype)
+                    dist.all_gather_into_tensor(out, loc)
+                else:
+                    out = torch.empty((self.world * samples.shape[0],) + tuple(samples.shape[1:]), dtype=samples.dtype, device=self.dev)
+                    # default: the gather is ordered on the compute stream (no RCCL kernel competes with a grad launch that
+                    # wants every CU); --async-gather overlaps it with the next chunk instead
+                    w = dist.all_gather_into_tensor(out, samples, async_op=self.async_gather)
+                    if self.async_gather:
+                        pending.append((w, out, samples))
             done += c
-        return state, pending
+        for w, _, _ in pending:
+            w.wait()
+        self.offset += n_steps
+        if own:
+            self.state = state
+        return state
 
-    def barrier():
-        torch.cuda.synchronize()
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def timed(self, n_steps):
+        """EXACTLY n_steps steps between barrier + synchronize on both sides; max over ranks (seconds)."""
+        torch, dist = self.torch, self.dist
+        self.barrier()
+        t0 = time.perf_counter()
+        self.run(n_steps)
+        self.barrier()
+        el = time.perf_counter() - t0
         if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+            t = torch.tensor([el], dtype=torch.float64, device='cpu' if self.gather_cpu else self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
 
-    state, pend = run(args.warmup, 0, state, True)
-    for w, _, _ in pend:
-        w.wait()
-    barrier()
-    t0 = time.perf_counter()
-    state, pend = run(args.steps, args.warmup, state, True)
-    for w, _, _ in pend:
-        w.wait()
-    barrier()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    finite = bool(torch.isfinite(state.position).all().item())
+    def measure(self, steps, warmup, budget_s=1.0, min_reps=5, max_reps=200):
+        self.run(warmup)
+        self.barrier()
+        first = self.timed(steps)                                   # also the estimate that sizes the repetitions
+        n_warm = int(min(max(0.3 / max(first / steps, 1e-9), 0), 20 * max(steps, 1)))
+        if n_warm > 0:
+            self.run(n_warm)                                        # clock warm-up, untimed
+        reps = int(min(max(min_reps, math.ceil(budget_s / max(first, 1e-9))), max_reps))
+        if self.dist is not None:                                   # every rank must run the same number of repetitions
+            t = self.torch.tensor([reps], dtype=self.torch.int64, device='cpu' if self.gather_cpu else self.dev)
+            self.dist.broadcast(t, 0)
+            reps = int(t.item())
+        times = [self.timed(steps) for _ in range(reps)]
+        return {'median': statistics.median(times), 'min': min(times), 'max': max(times), 'first': first, 'reps': reps}
 
-    # ---- dominant kernel: HIP events around every grad launch, same workload ----------
-    roof = None
-    if rank == 0 and not args.no_kernel_timing:
-        k_steps = min(args.steps, 200)
+    def roofline(self, k_steps, args):
+        """HIP events around every grad launch on the launch stream, same workload, separate pass (events inside the
+        timed pass would perturb `value`)."""
+        from mile_amd.engine import IntegratorState
+        eng, spec, E = self.eng, self.spec, self.E
         eng.grad_timing_begin()
-        state2, _ = run(k_steps, args.warmup + args.steps, IntegratorStateClone(state), False)
-        torch.cuda.synchronize()
+        self.run(k_steps, IntegratorState(*(t.clone() for t in self.state)), collect=False)
+        self.torch.cuda.synchronize()
         ms, n_launch = eng.grad_timing_end()
-        flops = grad_flops_per_particle(spec.in_features, spec.hidden_structure, N) * E
+        flops = grad_flops_per_particle(spec.in_features, spec.hidden_structure, self.N) * E
         avg_s = ms * 1e-3 / max(n_launch, 1)
         achieved = flops / avg_s / 1e12
         info = eng.grad_launch_info(E)
-        traffic = None   # PMC counters cannot be read from inside the run: last committed measurement
-        tj = ROOT / 'profiles' / 'r01' / 'traffic.json'
-        if tj.exists() and args.workload == 'B2' and E == E_PER_GPU and info['kernel'] == 'k_grad_w64':
-            traffic = json.loads(tj.read_text())['hbm_bytes_per_launch']
-        peak = wl['peak'] if eng.grad_kernel == 'mfma_w128_bf16' or args.workload == 'B2' else PEAK_FP32_MFMA_TFLOPS
+        traffic = None   # PMC counters cannot be read from inside the run: last committed measurement of this kernel
+        for rdir in ('r02', 'r01'):
+            tj = ROOT / 'profiles' / rdir / 'traffic.json'
+            if tj.exists() and self.name == 'B2' and E == WORKLOADS['B2']['ensemble'] and info['kernel'] == 'k_grad_w64':
+                traffic = json.loads(tj.read_text())['hbm_bytes_per_launch']
+                break
+        peak = self.wl['peak'] if eng.grad_kernel == 'mfma_w128_bf16' or self.name == 'B2' else PEAK_FP32_MFMA_TFLOPS
         roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak,
                 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic,
                 'kernel': info['kernel'], 'grid': list(info['grid']), 'lds_bytes': info['lds_bytes'],
@@ -236,15 +283,110 @@ def main():
             roof['mix'] = 'hidden-layer products as 6 bf16 MFMA products of exact 3-term bf16 splits (fp32-faithful)'
             roof['peak_mix_bound'] = round(peak * clk_fp32 / clk_mix, 1)
             roof['frac_of_mix_bound'] = round(achieved / (peak * clk_fp32 / clk_mix), 4)
+        return roof
+
+    def cpu(self):
+        Ec = self.E if self.wl['cpu_particles'] is None else min(self.E, self.wl['cpu_particles'])   # bounded sample
+        prob1 = {k: (v[:Ec] if k in ('theta0', 'u0', 'eps', 'L') else v) for k, v in self.prob.items()}
+        return cpu_baseline(self.spec_o, prob1, self.oracle, self.wl['cpu_seconds'])
+
+    def dtype(self):
+        return self.wl['dtype'] if self.eng.grad_kernel == 'mfma_w128_bf16' or self.name == 'B2' else 'f32'
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--workload', default=WORKLOAD, choices=sorted(WORKLOADS))
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=None)
+    ap.add_argument('--ensemble', type=int, default=None, help='particles per GPU')
+    ap.add_argument('--grad-kernel', default=None)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the bounded B3 leg of the default run')
+    ap.add_argument('--async-gather', action='store_true',
+                    help='N > 1: overlap each chunk\'s RCCL all-gather with the next chunk (default: ordered on the compute stream)')
+    ap.add_argument('--force-dist', action='store_true', help='init the process group even for 1 rank (rehearsal)')
+    ap.add_argument('--rehearse-one-gpu', action='store_true',
+                    help='all ranks share cuda:0 and talk over gloo (rehearsal of the N-rank control flow on a 1-GPU box)')
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+
+    # ---- N > 1 and no launcher environment: become the launcher (before anything touches the GPU) ----
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    wl = WORKLOADS[args.workload]
+    args.steps = wl['steps'] if args.steps is None else args.steps
+    args.warmup = wl['warmup'] if args.warmup is None else args.warmup
+
+    # stdout carries exactly one JSON line: anything native libraries write to fd 1 (RCCL prints its version
+    # banner there) goes to stderr instead, and the result is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    import torch
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} '
+                         f'or run `python bench.py --gpus {args.gpus}` without a launcher environment')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)')
+    if args.rehearse_one_gpu:
+        local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f'rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f'cuda:{local_rank}')
+    dist = None
+    if world > 1 or args.force_dist:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        if args.rehearse_one_gpu:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        print(f'bench.py: rank {rank}/{world} on {dev} ({dist.get_backend()})', file=sys.stderr)
+
+    leg = Leg(args.workload, args, dist, rank, world, dev, gather_cpu=args.rehearse_one_gpu)
+    tm = leg.measure(args.steps, args.warmup)
+    el = tm['median']
+    finite = bool(torch.isfinite(leg.state.position).all().item())
+
+    roof = None
+    if rank == 0 and not args.no_kernel_timing:
+        roof = leg.roofline(min(max(args.steps, 100), 200), args)
     if dist is not None:
         dist.barrier()
 
+    secondary = None
+    if world == 1 and args.workload == 'B2' and not args.no_secondary and args.ensemble is None and args.grad_kernel is None:
+        # BASELINE configs[2] (B3), bounded: ~10 steps per repetition, 16 particles on the CPU side
+        name = 'B3'
+        leg2 = Leg(name, args, None, 0, 1, dev, gather_cpu=False)
+        k2 = 10
+        tm2 = leg2.measure(k2, 3, budget_s=0.5, min_reps=3, max_reps=5)
+        sec = {'metric': 'MCLMC integrator particle-steps/s', 'value': round(leg2.E * k2 / tm2['median'], 1),
+               'unit': 'particle-steps/s', 'ms_per_step': round(tm2['median'] / k2 * 1e3, 4), 'steps': k2, 'reps': tm2['reps'],
+               'dtype': leg2.dtype(), 'config': {'workload': leg2.wl['text'], 'ensemble_per_gpu': leg2.E,
+                                                 'grad_kernel': leg2.eng.grad_kernel,
+                                                 'finite': bool(torch.isfinite(leg2.state.position).all().item())},
+               'roofline': None if args.no_kernel_timing else leg2.roofline(k2, args),
+               'cpu_baseline': None if args.no_cpu_baseline else leg2.cpu()}
+        secondary = {name: sec}
+        del leg2
+
     if rank == 0:
-        cpu = None
-        if not args.no_cpu_baseline:
-            Ec = E if wl['cpu_particles'] is None else min(E, wl['cpu_particles'])   # bounded sample
-            prob1 = {k: (v[:Ec] if k in ('theta0', 'u0', 'eps', 'L') else v) for k, v in prob.items()}
-            cpu = cpu_baseline(spec_o, prob1, oracle)
+        cpu = None if args.no_cpu_baseline else leg.cpu()
+        E = leg.E
         value = E * world * args.steps / el
         out = {
             'metric': 'MCLMC integrator particle-steps/s (integrator-steps/s x ensemble size)',
@@ -257,26 +399,28 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': wl['dtype'] if eng.grad_kernel == 'mfma_w128_bf16' or args.workload == 'B2' else 'f32',
+            'dtype': leg.dtype(),
             'data': 'synthetic',
-            'config': {'workload': wl['text'],
+            'config': {'workload': leg.wl['text'],
                        'ensemble_per_gpu': E, 'ensemble_total': E * world, 'n_thinning': N_THINNING,
                        'integrator': 'isokinetic McLachlan, O-step-O refresh, 2 full-batch gradients/step',
-                       'noise': 'Philox4x32-10 counter RNG', 'grad_kernel': eng.grad_kernel,
-                       'parallelism': f'particles sharded {E}/GPU x {world}, async RCCL all-gather of kept samples',
+                       'noise': 'Philox4x32-10 counter RNG', 'grad_kernel': leg.eng.grad_kernel,
+                       'parallelism': f'particles sharded {E}/GPU x {world}, RCCL all-gather of kept samples per {CHUNK}-step chunk '
+                                      + ('(async, overlapping the next chunk)' if args.async_gather else '(ordered on the compute stream)'),
                        'finite': finite},
+            'timing': {'repetitions': tm['reps'], 'reported': 'median repetition of the K-step timed region',
+                       'ms_per_step_min': round(tm['min'] / args.steps * 1e3, 5),
+                       'ms_per_step_max': round(tm['max'] / args.steps * 1e3, 5),
+                       'ms_per_step_first': round(tm['first'] / args.steps * 1e3, 5)},
             'roofline': roof,
             'cpu_baseline': cpu,
         }
+        if secondary is not None:
+            out['secondary'] = secondary
         os.write(json_fd, (json.dumps(out) + '\n').encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def IntegratorStateClone(st):
-    from mile_amd.engine import IntegratorState
-    return IntegratorState(*(t.clone() for t in st))
 
 
 if __name__ == '__main__':

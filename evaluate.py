@@ -21,6 +21,7 @@ def main():
     ap.add_argument('--exp', '-e', required=True, help='experiment directory (holds config.yaml and samples/)')
     ap.add_argument('--split', default='test', choices=['train', 'valid', 'test'])
     ap.add_argument('--device', default='cuda:0')
+    ap.add_argument('--ess-params', type=int, default=256, help='size of the random parameter subset ESS is evaluated on')
     ap.add_argument('--drop-nonfinite', action='store_true',
                     help='leave out chains with non-finite samples (the reference would report NaN; default: keep them)')
     args = ap.parse_args()
@@ -48,6 +49,24 @@ def main():
            'lppd': float(lppd(pw).item()), 'nll_mean': float(-pw.mean().item()),
            'running_lppd_last': float(running_lppd(pw)[-1].item()),
            'nonfinite_chains_total': int(bad_chains.sum()), 'nonfinite_samples': int((~torch.isfinite(torch.from_numpy(samples)).all(dim=-1)).sum().item())}
+    # ESS and ESS/s (BASELINE.json's metric; src/inference/metrics.py:386-405 on a parameter subset): per-chain ESS of
+    # each selected parameter, summed over chains, min / median over the subset, per second of `time.sampling`
+    from mile_amd.metrics import effective_sample_size
+    ok = samples[~bad_chains] if (bad_chains.any() and not bad_chains.all()) else samples
+    rng = np.random.default_rng(0)
+    cols = np.sort(rng.choice(samples.shape[2], size=min(args.ess_params, samples.shape[2]), replace=False))
+    if ok.shape[1] >= 8:
+        ess = effective_sample_size(torch.from_numpy(np.ascontiguousarray(ok[:, :, cols])).to(args.device)).sum(dim=0).cpu().numpy()
+        t_sampling = None
+        log = exp / 'training.log'
+        if log.exists():
+            import re
+            m = re.findall(r'time\.sampling took ([0-9.]+) seconds', log.read_text())
+            t_sampling = float(m[-1]) if m else None
+        out.update({'ess_params': int(len(cols)), 'ess_min': float(np.nanmin(ess)), 'ess_median': float(np.nanmedian(ess)),
+                    'time_sampling_s': t_sampling,
+                    'ess_per_s_min': float(np.nanmin(ess) / t_sampling) if t_sampling else None,
+                    'ess_per_s_median': float(np.nanmedian(ess) / t_sampling) if t_sampling else None})
     (exp / 'metrics.json').write_text(json.dumps(out, indent=1) + '\n')
     print(json.dumps(out))
 

@@ -88,6 +88,9 @@ class FCNConfig:
                'hidden_structure must be a list of positive ints')
         _check(self.activation in ('sigmoid', 'relu', 'gelu', 'tanh', 'softmax', 'leaky_relu'),
                f'unknown activation {self.activation!r}')
+        # the reference's enum (config/models/base.py:25-39) has three more; the HIP kernels implement these
+        _check(self.activation in ('sigmoid', 'relu', 'tanh'),
+               f'activation {self.activation!r} is not implemented on the MI355X path (supported: relu, tanh, sigmoid)')
 
 
 @dataclass(frozen=True)
@@ -103,6 +106,9 @@ class LeNetConfig:
         _check(self.model == 'LeNet', f'Could not find model {self.model}.')
         _check(self.activation in ('sigmoid', 'relu', 'gelu', 'tanh', 'softmax', 'leaky_relu'),
                f'unknown activation {self.activation!r}')
+        # the reference's enum (config/models/base.py:25-39) has three more; the HIP kernels implement these
+        _check(self.activation in ('sigmoid', 'relu', 'tanh'),
+               f'activation {self.activation!r} is not implemented on the MI355X path (supported: relu, tanh, sigmoid)')
         _check(isinstance(self.out_dim, int) and self.out_dim > 0, 'out_dim must be a positive int')
 
 

@@ -7,6 +7,8 @@ workload instead of reading a file (path = '<N>x<F>').
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from mile_amd.config import DataConfig
@@ -27,6 +29,11 @@ class TabularLoader:
 
     def load_data(self, shuffle: bool, normalize: bool = True) -> np.ndarray:
         path = self.config.path
+        if self.config.source != 'synthetic' and not os.path.exists(path):
+            # relative paths of the shipped YAMLs ('data/airfoil.data') resolve against the repository root too
+            alt = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path)
+            if os.path.exists(alt):
+                path = alt
         if self.config.source == 'synthetic':
             N, F = (int(v) for v in path.lower().split('x'))
             X = self._rng.standard_normal((N, F))

@@ -41,6 +41,24 @@ def init_process_group(backend: str | None = None, device: torch.device | None =
     return dist
 
 
+def broadcast_object(obj_list: list, src: int = 0) -> list:
+    """dist.broadcast_object_list when a group is up; identity for one process."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast_object_list(obj_list, src=src)
+    return obj_list
+
+
+def gather_objects(obj) -> list:
+    """Every rank's object, rank order (all_gather_object); [obj] for one process."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        out = [None] * dist.get_world_size()
+        dist.all_gather_object(out, obj)
+        return out
+    return [obj]
+
+
 def gather_samples(samples: torch.Tensor, async_op: bool = False):
     """All-gather kept positions [K, E_local, d] -> [K, E_total, d] (rank-major chain order ==
     shard_chains order).  Equal E_local on every rank.  Returns (tensor, work|None)."""

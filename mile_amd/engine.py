@@ -304,6 +304,9 @@ class Engine:
             X = X.reshape(X.shape[0], -1).contiguous()
         if X.ndim != 2 or X.shape[1] != self.spec.in_features or y.shape != (X.shape[0],):
             raise ValueError('X must be [N, F] and y [N]')
+        if self.spec.task != 'regr' and y.numel():       # the kernels index the logits with the raw label
+            if int(y.min()) < 0 or int(y.max()) >= self.spec.hidden_structure[-1]:
+                raise ValueError('class labels out of range')
         out = torch.empty((th.shape[0], X.shape[0]), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.mile_pointwise_loglik(self._h, _ptr(th), th.shape[0], _ptr(X), _ptr(y), X.shape[0],

@@ -67,3 +67,36 @@ def running_lppd(lppd_pointwise: torch.Tensor) -> torch.Tensor:
     e = torch.exp(lppd_pointwise)
     cnt = torch.arange(1, e.shape[1] + 1, device=e.device, dtype=e.dtype)[None, :, None]
     return torch.log(torch.cumsum(e, dim=1) / cnt).mean(dim=-1).mean(dim=0)
+
+
+def rank_normalize_array(samples: torch.Tensor) -> torch.Tensor:
+    """metrics.py:226-244: overall ranks (average rank for ties) -> normal quantiles."""
+    flat = samples.reshape(-1).to(torch.float64)
+    n = flat.numel()
+    order = torch.argsort(flat, stable=True)
+    sv = flat[order]
+    ranks_sorted = torch.arange(1, n + 1, dtype=torch.float64, device=flat.device)
+    # average rank within runs of equal values (scipy.stats.rankdata method='average')
+    new_run = torch.ones(n, dtype=torch.bool, device=flat.device)
+    new_run[1:] = sv[1:] != sv[:-1]
+    run_id = torch.cumsum(new_run.to(torch.int64), 0) - 1
+    n_runs = int(run_id[-1].item()) + 1 if n else 0
+    sums = torch.zeros(n_runs, dtype=torch.float64, device=flat.device).index_add_(0, run_id, ranks_sorted)
+    cnts = torch.zeros(n_runs, dtype=torch.float64, device=flat.device).index_add_(0, run_id, torch.ones_like(ranks_sorted))
+    ranks = torch.empty_like(flat)
+    ranks[order] = (sums / cnts)[run_id]
+    tmp = (ranks - 0.375) / (n + 0.25)
+    return (math.sqrt(2.0) * torch.erfinv(2.0 * tmp - 1.0)).reshape(samples.shape).to(samples.dtype)
+
+
+def effective_sample_size(x: torch.Tensor, rank_normalize: bool = True) -> torch.Tensor:
+    """metrics.py:386-405: x [C, S, ...] -> per-chain ESS [C, ...].  Each trailing column is rank-normalised over
+    the pooled C*S draws, then every chain goes through the single-chain FFT/Geyer estimator (the reference calls
+    numpyro's; here the Stan-style estimator of mile_amd.diagnostics, the same one the tuner uses)."""
+    from mile_amd.diagnostics import effective_sample_size as ess1
+    C, S = x.shape[:2]
+    cols = x.reshape(C, S, -1)
+    if rank_normalize:
+        cols = torch.stack([rank_normalize_array(cols[:, :, k]) for k in range(cols.shape[2])], dim=2)
+    out = torch.stack([ess1(cols[c][None]) for c in range(C)])
+    return out.reshape(C, *x.shape[2:])

@@ -17,6 +17,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
+from mile_amd import distributed as mdist
 from mile_amd.sample_writer import WriterPool
 from mile_amd.kernels import KERNELS
 from mile_amd.probabilistic import resolve_target
@@ -84,9 +85,13 @@ def inference_loop(unnorm_log_posterior, config, rng_key, init_params, step_ids,
     saving_path.mkdir(parents=True, exist_ok=True)
     eps_host = parameters['step_size'].detach().cpu().numpy().reshape(-1)
     L_host = parameters['L'].detach().cpu().numpy().reshape(-1)
-    with open(saving_path.parent / 'warmup_params.txt', 'w') as f:      # sampling.py:92-97
-        f.write(','.join(str(v) for v in eps_host) + '\n')
-        f.write(','.join(str(v) for v in L_host) + '\n')
+    # one file for the whole chain group (sampling.py:92-97): ranks hold disjoint chains, rank 0 writes all of them
+    # in chain order (shard_chains is a contiguous rank-major partition)
+    parts = mdist.gather_objects((eps_host, L_host))
+    if mdist.world()[0] == 0:
+        with open(saving_path.parent / 'warmup_params.txt', 'w') as f:
+            f.write(','.join(str(v) for p in parts for v in p[0]) + '\n')
+            f.write(','.join(str(v) for p in parts for v in p[1]) + '\n')
     torch.cuda.synchronize(eng.device)
     logger.info(f'> Warmup sampling completed successfully. ({time.time() - t_w0:.2f} s)')
 
@@ -124,8 +129,9 @@ def inference_loop(unnorm_log_posterior, config, rng_key, init_params, step_ids,
     logger.info(f'> stepping {t_s1 - t_s0:.2f} s, waiting for sample files {time.time() - t_s1:.2f} s '
                 f'({n_files} files, {io_workers} writer processes)')
     logger.info(f'> {config.name} Sampling completed successfully.')
-    with open(saving_path / 'info.pkl', 'wb') as f:                       # sampling.py:212-216
-        pickle.dump(info, f)
+    if mdist.world()[0] == 0:
+        with open(saving_path / 'info.pkl', 'wb') as f:                   # sampling.py:212-216
+            pickle.dump(info, f)
     if return_samples:
         return torch.cat(kept_all, dim=0) if kept_all else None
     return None

@@ -49,7 +49,15 @@ class BDETrainer:
     def __init__(self, config: Config, chains_per_group: int | None = None):
         assert isinstance(config, Config)
         self.rank, self.world_size, self.local_rank = mdist.world()
-        self.config = config.setup_dir() if self.rank == 0 else config
+        # Rank 0 resolves the experiment directory (setup_dir renames the experiment when the directory already
+        # exists); every other rank must derive its paths from THAT name, or it writes into the previous run.
+        if self.world_size > 1:
+            mdist.init_process_group()
+            name = [config.setup_dir().experiment_name if self.rank == 0 else None]
+            mdist.broadcast_object(name)
+            self.config = config.replace(experiment_name=name[0])
+        else:
+            self.config = config.setup_dir()
         self._key = PRNGKey(config.rng)
         self.n_chains = config.n_chains
         # all chains of a rank advance together in one ensemble launch; `chains_per_group`
@@ -165,9 +173,9 @@ class BDETrainer:
                 y = torch.from_numpy(np.ascontiguousarray(self.loader.train_y))
             log_post = self.prob_model.bind(x, y)
             for step in self.train_plan:
+                if len(step) < self.world_size:        # every rank takes part in the per-group collectives
+                    raise ValueError(f'a chain group of {len(step)} chains cannot be sharded over {self.world_size} ranks')
                 mine = mdist.shard_chains(step, self.world_size, self.rank)
-                if len(mine) == 0:
-                    continue
                 logger.info(f'\t| Starting Sampling for chains {mine}')
                 if chains:
                     params = load_params_batch([chains[i] for i in mine], self.prob_model.spec)

@@ -162,8 +162,10 @@ def mclmc_find_L_and_step_size(eng, state: IntegratorState, rng_key, *, tune1_st
         L = variances.sum(dim=1).sqrt()
         if diagonal_preconditioning:
             sqrt_diag_cov = variances.sqrt()
+            # the re-adjustment keeps running with the phase-1 L (params.L is not replaced before run_steps,
+            # warmup.py:389-401); L = sqrt(dim) is what gets returned (:392,403)
             L = torch.full((E,), math.sqrt(d), **f32)
-            L_cur[0], sdc_cur[0] = L, sqrt_diag_cov
+            sdc_cur[0] = sqrt_diag_cov
             steps = tune2_steps // 3
             state, eps, _ = run_steps(state, eps, [1.0] * steps, part1_key.fold_in(1).seed, tune1_steps + tune2_steps)
     L_cur[0] = L

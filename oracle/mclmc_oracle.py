@@ -644,8 +644,10 @@ def tune_phase12(logdensity_and_grad, state: State, noise_fn, tune1: int, tune2:
         L = np.sqrt(var.sum(axis=-1)).astype(dt)
         if diagonal_preconditioning:
             sdc = np.sqrt(var).astype(dt)
+            # warmup.py:389-401: only `params.sqrt_diag_cov` is replaced before the re-adjustment run, so its kernel steps
+            # still use params.L = max(sqrt(d), 15) of phase 1; sqrt(d) is the RETURNED L only (differs for d < 225).
             L = np.full(E, math.sqrt(d), dtype=dt)
-            L_cur[0], sdc_cur[0] = L, sdc
+            sdc_cur[0] = sdc
             steps = tune2 // 3
             state, eps, _ = run_steps(state, eps, [1.0] * steps, noise_offset + tune1 + tune2)
     return TunerResult(state, L, eps, sdc, trace)

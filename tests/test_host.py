@@ -441,3 +441,168 @@ def test_sharding_and_sample_collection_world_size_2(tmp_path):
     port = 29600 + os.getpid() % 300
     mp.spawn(_dist_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / 'ok0').exists() and (tmp_path / 'ok1').exists()
+
+
+def _trainer_worker(rank, ws, port, tmp):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as dist
+    from mile_amd import distributed as md
+    from mile_amd.config import Config
+    from mile_amd.trainer import BDETrainer
+    cfg = Config.from_file(ROOT / 'experiments' / 'mclmc_airfoil_b1.yaml').replace(saving_dir=str(tmp), logging=False)
+    names = []
+    for _ in range(2):                       # the second construction finds the directory and renames the experiment
+        t = BDETrainer(cfg)
+        names.append(t.config.experiment_name)
+        dist.barrier()
+    assert names[0] == 'mclmc_airfoil_3x64' and names[1].startswith('mclmc_airfoil_3x64_'), names
+    both = md.gather_objects(names)
+    assert both[0] == both[1], both          # every rank derives its paths from rank 0's resolved name
+    assert (Path(tmp) / names[1] / 'config.yaml').exists()
+    # the per-group files: every rank contributes its chains' values, rank 0 writes them in chain order
+    parts = md.gather_objects((np.full(2, rank, dtype=np.float32), np.full(2, 10 + rank, dtype=np.float32)))
+    assert [float(v) for p in parts for v in p[0]] == [0.0, 0.0, 1.0, 1.0]
+    torch.save(torch.tensor(1), Path(tmp) / f'ok{rank}')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_ranks_share_the_resolved_experiment_dir_world_size_2(tmp_path):
+    """rank 0's setup_dir may rename the experiment; ranks > 0 must not keep the old name."""
+    import torch.multiprocessing as mp
+    port = 29950 + os.getpid() % 40
+    mp.spawn(_trainer_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / 'ok0').exists() and (tmp_path / 'ok1').exists()
+
+
+def _gather_worker(rank, ws, port, tmp):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as dist
+    from mile_amd import distributed as md
+    dist.init_process_group('gloo', rank=rank, world_size=ws)
+    ids = md.shard_chains(np.arange(8), ws, rank)
+    g = torch.Generator().manual_seed(1)
+    for K, async_op in ((1, False), (5, False), (5, True), (3, True)):      # K kept samples in the chunk
+        full = torch.randn(K, 8, 11, generator=g)                          # [K, E, d], chain e = column e
+        mine = full[:, ids[0]:ids[-1] + 1].contiguous()
+        out, work = md.gather_samples(mine, async_op=async_op)
+        if work is not None:
+            work.wait()
+        got = out.contiguous()
+        assert got.shape == full.shape and torch.equal(got, full), (K, async_op)   # sample k, chain order == shard_chains order
+    torch.save(torch.tensor(1), Path(tmp) / f'ok{rank}')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gathered_sample_order_for_several_kept_samples_per_chunk_world_size_2(tmp_path):
+    import torch.multiprocessing as mp
+    port = 29900 + os.getpid() % 40
+    mp.spawn(_gather_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / 'ok0').exists() and (tmp_path / 'ok1').exists()
+
+
+def test_bench_gpus_n_starts_n_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no RANK in the environment becomes the launcher: two child ranks, the parent
+    never touches the GPU, a failing rank makes the parent fail.  (No GPU here: both ranks refuse loudly.)"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1'],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert 'started 2 ranks' in r.stderr
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and 'needs an MI355X' in r.stderr and r.stdout.strip() == ''
+    # under a launcher environment the world size must match --gpus
+    env2 = dict(env, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    r2 = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', '2'], capture_output=True, text=True, env=env2, timeout=300)
+    assert r2.returncode != 0 and 'WORLD_SIZE=1' in r2.stderr
+
+
+def test_airfoil_table_loads_with_reference_split():
+    """The shipped data fixture behind experiments/mclmc_airfoil_b1/b2.yaml (data/README.md): 1503 x 6, z-scored
+    including the target (tabular.py:146-147), 70 / 10 / 20 split -> N_train = 1052."""
+    from mile_amd.config import Config
+    from mile_amd.dataset import TabularLoader
+    raw = np.genfromtxt(ROOT / 'data' / 'airfoil.data', delimiter=' ')
+    assert raw.shape == (1503, 6) and np.isfinite(raw).all()
+    assert raw[0].tolist() == [800.0, 0.0, 0.3048, 71.3, 0.00266337, 126.201]
+    cfg = Config.from_file(ROOT / 'experiments' / 'mclmc_airfoil_b2.yaml')
+    assert cfg.data.path == 'data/airfoil.data' and cfg.data.source == 'local'
+    cwd = os.getcwd()
+    try:
+        os.chdir('/')                                   # relative path resolves against the repository root too
+        ld = TabularLoader(cfg.data, rng=cfg.rng)
+    finally:
+        os.chdir(cwd)
+    assert ld.train_x.shape == (1052, 5) and ld.valid_x.shape == (150, 5) and ld.test_x.shape == (301, 5)
+    allx = np.concatenate([ld.train_x, ld.valid_x, ld.test_x]); ally = np.concatenate([ld.train_y, ld.valid_y, ld.test_y])
+    assert np.abs(allx.mean(0)).max() < 1e-4 and np.abs(allx.std(0) - 1).max() < 1e-4
+    assert abs(ally.mean()) < 1e-4 and abs(ally.std() - 1) < 1e-4
+
+
+def test_unsupported_activations_are_config_errors():
+    from mile_amd.config import Config, ConfigError
+    d = Config.from_file(ROOT / 'experiments' / 'mclmc_airfoil_b1.yaml').to_dict()
+    for act in ('gelu', 'leaky_relu', 'softmax'):
+        d['model']['activation'] = act
+        with pytest.raises(ConfigError, match='not implemented'):
+            Config.from_dict(d)
+
+
+def test_chain_ess_metric_rank_normalised():
+    """src/inference/metrics.py:226-244,386-405: pooled rank normalisation, then one single-chain ESS per chain."""
+    from scipy.stats import norm, rankdata
+    from mile_amd.metrics import effective_sample_size, rank_normalize_array
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 400, 2, generator=g, dtype=torch.float64)
+    x[0, 0, 0] = x[1, 1, 0]                                                  # a tie gets the average rank
+    r = rank_normalize_array(x[:, :, 0]).numpy()
+    ref = norm.ppf((rankdata(x[:, :, 0].numpy(), axis=None).reshape(3, 400) - 0.375) / (1200 + 0.25))
+    assert np.abs(r - ref).max() < 1e-9
+    ess = effective_sample_size(x)
+    assert ess.shape == (3, 2) and 250 < float(ess.min()) and float(ess.max()) < 650      # white noise: ESS ~ S
+    rho = 0.9                                                                # AR(1): ESS ~ S (1 - rho) / (1 + rho)
+    z = torch.randn(2, 4000, generator=g, dtype=torch.float64)
+    y = torch.zeros_like(z)
+    for t in range(1, 4000):
+        y[:, t] = rho * y[:, t - 1] + z[:, t]
+    e2 = effective_sample_size(y[:, :, None])[:, 0]
+    assert torch.all((e2 > 0.5 * 4000 * 0.1 / 1.9) & (e2 < 2.0 * 4000 * 0.1 / 1.9)), e2
+    # the oracle's estimator on the same rank-normalised column
+    rn = rank_normalize_array(y).numpy()
+    eo = np.stack([np.asarray(O.effective_sample_size(rn[c][None, :, None])).reshape(-1)[0] for c in range(2)])
+    assert np.abs(e2.numpy() - eo).max() / eo.max() < 1e-6
+
+
+class _FakeEngine:
+    """Records what the tuner asks of the engine (no GPU): eng.tune advances nothing."""
+
+    def __init__(self, d):
+        self.device, self.d, self.supports_device_tuner = torch.device('cpu'), d, True
+        self.tune_calls = []
+
+    def tune(self, state, tuner, L, n_steps, **kw):
+        self.tune_calls.append((torch.as_tensor(L).clone(), n_steps, kw['sqrt_diag_cov']))
+        tuner['stream_average'][:, 0] = 1.0
+        tuner['stream_average'][:, 1] = 5.0          # variances = 4 -> sqrt_diag_cov = 2
+
+
+def test_readjustment_runs_with_the_phase1_L_and_returns_sqrt_dim():
+    """src/training/warmup.py:389-403: under diagonal_preconditioning only params.sqrt_diag_cov is
+    replaced before the re-adjustment run_steps, so its kernel steps keep L = max(sqrt(d), 15); sqrt(d) is returned."""
+    from mile_amd.engine import IntegratorState
+    from mile_amd.warmup import mclmc_find_L_and_step_size
+    E, d = 2, 138                                    # d < 225: sqrt(d) = 11.7 < 15
+    eng = _FakeEngine(d)
+    st = IntegratorState(torch.zeros(E, d), torch.zeros(E, d), torch.zeros(E), torch.zeros(E, d))
+    _, params = mclmc_find_L_and_step_size(eng, st, 0, tune1_steps=8, tune2_steps=6, tune3_steps=0, step_size_init=0.01,
+                                           desired_energy_var_start=0.5, desired_energy_var_end=0.1, trust_in_estimate=1.5,
+                                           num_effective_samples=100, diagonal_preconditioning=True)
+    (L1, n1, s1), (L2, n2, s2) = eng.tune_calls
+    assert n1 == 14 and s1 is None and torch.all(L1 == 15.0)
+    assert n2 == 2 and torch.all(L2 == 15.0) and torch.allclose(s2, torch.full((E, d), 2.0))   # phase-1 L, new preconditioner
+    assert torch.allclose(params.L, torch.full((E,), math.sqrt(d))) and torch.allclose(params.sqrt_diag_cov, s2)

@@ -324,3 +324,29 @@ def test_golden_bf16_recipe_and_lenet():
     ls = LN.LeNetSpec(2, 12, 14, 3, activation='tanh')
     lp, g = LN.logpost_and_grad(ls, z['theta0'].astype(np.float64), z['X'], z['y'])
     assert np.allclose(lp, z['logp'], rtol=1e-12, atol=0) and np.allclose(g, z['grad'], rtol=1e-10, atol=1e-12)
+
+
+def test_tuner_readjustment_keeps_phase1_L(monkeypatch):
+    """src/training/warmup.py:389-403: with diagonal_preconditioning the extra tune2 // 3 steps run with the L of
+    phase 1, max(sqrt(d), 15) -- `params` only had sqrt_diag_cov replaced -- and sqrt(d) is what is returned.
+    d = 10 < 225, so the two differ."""
+    d, E, t1, t2 = 10, 3, 12, 9
+    rng = np.random.default_rng(0)
+    x0 = rng.standard_normal((E, d))
+    st = O.mclmc_init(_gauss_target, x0, rng.standard_normal((E, d)))
+    seen = []
+    real = O.mclmc_step
+
+    def spy(f, state, eps, L, z1, z2, sdc=None, refresh='O-step-O'):
+        seen.append((np.array(L, copy=True), None if sdc is None else np.array(sdc, copy=True)))
+        return real(f, state, eps, L, z1, z2, sdc, refresh)
+    monkeypatch.setattr(O, 'mclmc_step', spy)
+    noise = lambda i: (np.random.default_rng(100 + i).standard_normal((E, d)), np.random.default_rng(500 + i).standard_normal((E, d)))
+    res = O.tune_phase12(_gauss_target, st, noise, t1, t2, step_size_init=0.05, desired_energy_var_start=0.5,
+                         desired_energy_var_end=0.1, trust_in_estimate=1.5, num_effective_samples=100,
+                         diagonal_preconditioning=True)
+    assert len(seen) == t1 + t2 + t2 // 3
+    assert all(np.all(L == 15.0) for L, _ in seen)                       # every kernel step, re-adjustment included
+    assert all(np.all(s == 1.0) for _, s in seen[:t1 + t2])
+    assert all(np.allclose(s, res.sqrt_diag_cov) for _, s in seen[t1 + t2:]) and not np.allclose(res.sqrt_diag_cov, 1.0)
+    assert np.allclose(res.L, math.sqrt(d))
