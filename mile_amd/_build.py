@@ -12,9 +12,14 @@ from pathlib import Path
 PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / 'csrc'
 LIB_PATH = PKG_DIR / 'libmile_hip.so'
-SOURCES = ['mile_hip.hip']
+# translation units and their extra flags.  -amdgpu-mfma-vgpr-form: MFMA results that the VALU consumes next land in VGPRs
+# instead of AGPRs (fewer v_accvgpr moves and spills in the register-bound grad kernels; measured +0.5 % w64, +2 % w128b);
+# mile_w64_fq2.hip is built without it (hipcc 7.2 crashes on k_grad_w64<3,2,true> with it).
+VGPR_FORM = ['-mllvm', '-amdgpu-mfma-vgpr-form']
+SOURCES = {'mile_hip.hip': VGPR_FORM, 'mile_w64_fq2.hip': []}
 HEADERS = ['mile_device.h', 'mile_grad_generic.h', 'mile_grad_w64.h', 'mile_grad_w64_block.inc', 'mile_bf16_frag.h',
            'mile_grad_w128b.h', 'mile_grad_gemm.h', 'mile_lenet.h', 'mile_predict.h', 'mile_update.h']
+OBJ_DIR = PKG_DIR / 'csrc' / '_obj'
 
 
 def _hipcc() -> str:
@@ -28,24 +33,40 @@ def needs_build() -> bool:
     if not LIB_PATH.exists():
         return True
     t = LIB_PATH.stat().st_mtime
-    deps = [CSRC / f for f in SOURCES + HEADERS] + [PKG_DIR.parent / 'include' / 'mile_hip.h']
+    deps = [CSRC / f for f in list(SOURCES) + HEADERS] + [PKG_DIR.parent / 'include' / 'mile_hip.h']
     return any(p.stat().st_mtime > t for p in deps)
 
 
 def build_library(force: bool = False, verbose: bool = False) -> Path:
-    """hipcc --offload-arch=gfx950 -shared -fPIC -> mile_amd/libmile_hip.so."""
+    """hipcc --offload-arch=gfx950: one object per translation unit (compiled concurrently), then
+    -shared -> mile_amd/libmile_hip.so."""
     if not force and not needs_build():
         return LIB_PATH
     extra = os.environ.get('MILE_HIPCC_FLAGS', '').split()          # dev: extra compiler flags for experiments
-    # -amdgpu-mfma-vgpr-form: MFMA results that the VALU consumes next land in VGPRs instead of AGPRs (fewer
-    # v_accvgpr moves and spills in the register-bound grad kernels; measured +0.5 % w64, +2 % w128b)
-    cmd = [_hipcc(), '-O3', '--offload-arch=gfx950', '-std=c++17', '-shared', '-fPIC', '-mllvm', '-amdgpu-mfma-vgpr-form'] + extra + \
-          ['-o', str(LIB_PATH)] + [str(CSRC / f) for f in SOURCES] + ['-ldl']
+    OBJ_DIR.mkdir(exist_ok=True)
+    base = [_hipcc(), '-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC']
+    jobs = []
+    for src, flags in SOURCES.items():
+        obj = OBJ_DIR / (Path(src).stem + '.o')
+        cmd = base + flags + extra + ['-c', str(CSRC / src), '-o', str(obj)]
+        if verbose:
+            print(' '.join(cmd))
+        jobs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    objs = []
+    for src, obj, proc in jobs:
+        out, err = proc.communicate()
+        if proc.returncode != 0:
+            for _, _, other in jobs:
+                if other.poll() is None:
+                    other.kill()
+            raise RuntimeError(f'hipcc failed on {src}:\n{out}\n{err}')
+        objs.append(str(obj))
+    link = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', str(LIB_PATH)] + objs + ['-ldl']
     if verbose:
-        print(' '.join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
+        print(' '.join(link))
+    res = subprocess.run(link, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError(f'hipcc failed:\n{res.stdout}\n{res.stderr}')
+        raise RuntimeError(f'hipcc link failed:\n{res.stdout}\n{res.stderr}')
     return LIB_PATH
 
 

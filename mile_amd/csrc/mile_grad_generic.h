@@ -39,7 +39,7 @@ __device__ __forceinline__ float row_loss_regr(float mu, float sr, float yv, flo
   return ll;
 }
 
-__global__ __launch_bounds__(256) void k_grad_generic(const GradParams p) {
+static __global__ __launch_bounds__(256) void k_grad_generic(const GradParams p) {
   extern __shared__ float lds[];
   const DevSpec &sp = p.spec;
   const int tid = threadIdx.x, nt = blockDim.x;

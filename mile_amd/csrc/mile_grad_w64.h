@@ -35,6 +35,40 @@
 #include "mile_bf16_frag.h"
 #include "mile_device.h"
 #include "mile_grad_generic.h"
+#include "mile_update.h"
+
+// Fused integrator epilogue of the SPLIT kernel: when `enabled`, the workgroup of a particle that
+// finishes LAST runs everything between this gradient and the next one (upd_fast_body: the B / O chain, record point, tuner,
+// position update) right here instead of in a separate k_update_fast launch.  Hand-off of the S partial-gradient slabs =
+// the counter form of cdna_hip_programming.md section 6 Guideline 16, placement-independent: every slab / llpart byte is
+// stored sc1 (write-through), every storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier, one lane draws a ticket with
+// a relaxed agent-scope fetch_add; the workgroup that draws S-1 reads all slabs with sc1 loads (ld4_slab<.., COH = true>).
+struct W64Fuse {
+  UpdParams upd;
+  int32_t *arrive;    // [E] tickets, zero before the launch; the last arriver re-zeroes its particle's word
+  int32_t enabled;
+  int32_t kind;       // upd_kind(upd): UPD_KIND_MID / UPD_KIND_REC select the compile-time-specialised body, -1 the general one
+};
+// Kernels built without the epilogue take this instead (the fp32-MFMA form, and F > 8: with the epilogue in -- or even just
+// the larger argument block -- hipcc 7.2 crashes in its AGPR-copy rewrite on the heavily spilling k_grad_w64<3,2,true>).
+struct W64NoFuse {
+  int32_t enabled;
+};
+// MEASURED AND NOT ENABLED BY DEFAULT (build with MILE_HIPCC_FLAGS=-DMILE_W64_EPILOGUE to compile it in): on B2 the
+// epilogue costs 8.6 us (mid-step) / 15.8 us (record point) inside the grad launch -- 4.7 us of it the last arriver's sc1
+// reads of 140 KB with four waves, and its Philox chains run at one wave per SIMD -- against 14.8 us for BOTH stand-alone
+// k_update_fast launches (768 threads per particle, boundaries included): 154.1 vs 150.6 us per MCLMC step
+// (profiles/r02/03_fused_epilogue_experiment.md).
+#ifdef MILE_W64_EPILOGUE
+#define MILE_W64_EPILOGUE_ON 1
+#else
+#define MILE_W64_EPILOGUE_ON 0
+#endif
+template <int FQ, bool SPLIT>
+struct W64FuseArg {
+  static constexpr bool FUSABLE = MILE_W64_EPILOGUE_ON && SPLIT && FQ == 1;
+  using type = std::conditional_t<FUSABLE, W64Fuse, W64NoFuse>;
+};
 
 #define W64_RS 68  // row stride (floats) of every padded LDS image
 
@@ -190,7 +224,7 @@ struct W64Layout {
 };
 
 template <int NH, int FQ, bool SPLIT = false>
-__global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p) {
+__global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p, const typename W64FuseArg<FQ, SPLIT>::type fz) {
   using LY = W64Layout<NH, FQ, SPLIT>;
   static_assert(!SPLIT || NH >= 2, "SPLIT needs a hidden->hidden layer");
   constexpr int FP = LY::FP;
@@ -202,12 +236,38 @@ __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p) {
   const int d = sp.d, F = sp.in_features;
   const float *th = p.theta + (size_t)e * d;
   float *slab = p.slabs + ((size_t)e * p.S + s) * p.dp;
+  // slab / llpart stores: plain, or sc1 (write-through) when the update runs as this launch's epilogue
+  constexpr bool FUSABLE = W64FuseArg<FQ, SPLIT>::FUSABLE;
+  const bool fuse = FUSABLE && fz.enabled;
+  auto st_quad = [&](int off, const f32x4 v) {
+    if constexpr (FUSABLE) {
+      if (fuse) {
+        const __amdgpu_buffer_rsrc_t slab_rs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, p.dp * 4, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(upd_u32x4, v), slab_rs, off * 4, 0, 16);   // aux 16 = sc1
+        return;
+      }
+    }
+    *(f32x4 *)(slab + off) = v;
+  };
+  auto st_one = [&](float *q, const float v) {
+    if constexpr (FUSABLE) {
+      if (fuse) {
+        __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+    }
+    *q = v;
+  };
 
   float *WIMG = lds + LY::WIMG, *W1IMG = lds + LY::W1IMG, *BIAS = lds + LY::BIAS;
   float *WO = lds + LY::WO, *BO = lds + LY::BO;
   float *wv = lds + LY::WAVE0 + wave * LY::WAVE_SZ;
   float *img = wv + LY::IMG, *xt = wv + LY::XT, *dout_l = wv + LY::DOUT;
 
+  // dev (MILE_DEBUG=32): 100 MHz timestamps per workgroup: start, main loop done, slab stored, ticket drawn, epilogue done
+  const bool stamp = (p.dbg & 32) && p.dbg_buf && tid == 0;
+  long long *stamps = p.dbg_buf + ((size_t)e * p.S + s) * 16;
+  if (stamp) stamps[0] = wall_clock64();
   // ---- stage this particle's weights in LDS --------------------------------------
   char *BIMG = reinterpret_cast<char *>(WIMG);   // SPLIT: term t of image set s at BIMG + (3 s + t) * 16384
   if (!(p.dbg & 2))
@@ -344,6 +404,7 @@ __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p) {
 
   // ---- reduce the four waves' accumulators through LDS, write the slab -------------
   __syncthreads();  // weights and images are dead from here on; LDS is reused
+  if (stamp) stamps[1] = wall_clock64();
   float *RED = lds;
   if (p.dbg & 4) return;
   // one round for all hidden->hidden matrices: RED[l][wave][in][68]
@@ -372,13 +433,13 @@ __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p) {
         const int o = (q >> 4) * W64_RS + 4 * (q & 15);
         const f32x4 v = (*(const f32x4 *)(R0 + o) + *(const f32x4 *)(R0 + 64 * W64_RS + o)) +
                         (*(const f32x4 *)(R0 + 2 * 64 * W64_RS + o) + *(const f32x4 *)(R0 + 3 * 64 * W64_RS + o));
-        *(f32x4 *)(out + 4 * q) = v;
+        st_quad(sp.w_off[l + 1] + 4 * q, v);
       }
     } else {
 #pragma unroll 4
       for (int idx = tid; idx < 4096; idx += 256) {
         const int o = (idx >> 6) * W64_RS + (idx & 63);
-        out[idx] = (R0[o] + R0[64 * W64_RS + o]) + (R0[2 * 64 * W64_RS + o] + R0[3 * 64 * W64_RS + o]);
+        st_one(out + idx, (R0[o] + R0[64 * W64_RS + o]) + (R0[2 * 64 * W64_RS + o] + R0[3 * 64 * W64_RS + o]));
       }
     }
   }
@@ -419,10 +480,45 @@ __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p) {
   __syncthreads();
   for (int k = tid; k < SM_LL + 1; k += 256) {
     const float v = (RED[k] + RED[SM_SZ + k]) + (RED[2 * SM_SZ + k] + RED[3 * SM_SZ + k]);
-    if (k < SM_W1) slab[sp.b_off[k >> 6] + (k & 63)] = v;
-    else if (k < SM_WO) { if ((k - SM_W1) < F * 64) slab[sp.w_off[0] + (k - SM_W1)] = v; }
-    else if (k < SM_BO) slab[sp.w_off[NH] + (k - SM_WO)] = v;
-    else if (k < SM_LL) slab[sp.b_off[NH] + (k - SM_BO)] = v;
-    else p.llpart[(size_t)e * p.S + s] = v;
+    if (k < SM_W1) st_one(slab + sp.b_off[k >> 6] + (k & 63), v);
+    else if (k < SM_WO) { if ((k - SM_W1) < F * 64) st_one(slab + sp.w_off[0] + (k - SM_W1), v); }
+    else if (k < SM_BO) st_one(slab + sp.w_off[NH] + (k - SM_WO), v);
+    else if (k < SM_LL) st_one(slab + sp.b_off[NH] + (k - SM_BO), v);
+    else st_one(p.llpart + (size_t)e * p.S + s, v);
+  }
+
+  // ---- fused integrator epilogue: the particle's last-arriving workgroup runs the update -------------------
+  if (stamp) { stamps[2] = wall_clock64(); stamps[3] = 0; stamps[4] = 0; }
+  if constexpr (FUSABLE) {
+    if (fuse) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // EVERY storing wave drains its sc1 stores ...
+      __syncthreads();                                       // ... before the one lane that signals for all of them
+      int *lflag = reinterpret_cast<int *>(lds);             // (the reduction scratch is dead behind this barrier)
+      if (tid == 0) {
+        const int old = __hip_atomic_fetch_add(fz.arrive + e, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == p.S - 1;
+        if (last) __hip_atomic_store(fz.arrive + e, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        *lflag = last;
+      }
+      __syncthreads();
+      if (stamp) stamps[3] = wall_clock64();
+      if (*lflag) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: keeps the compiler from hoisting loads
+        // quads per thread at 256 threads for the largest d this (NH, FQ) can have
+        constexpr int NKF = ((8 * FQ * 64 + 64 + (NH - 1) * 4160 + 130) / 4 + 255) / 256;
+        // inlined: every UpdParams field is then a scalar load from the kernel-argument segment.  (Out of line, reached
+        // through a generic pointer, each field was re-read with a flat load after every store: 24 us instead of 7.)
+        float(*ured)[UPD_NSUM + 1] = reinterpret_cast<float(*)[UPD_NSUM + 1]>(lds + 16);
+        float *ubc = lds + 16 + 4 * (UPD_NSUM + 1);
+        long long *ust = stamp ? stamps + 5 : nullptr;
+        if (fz.kind == UPD_KIND_MID) upd_fast_body<NKF, 2, false, true, UPD_KIND_MID>(fz.upd, e, tid, 256, ured, ubc, ust);
+        else if (fz.kind == UPD_KIND_REC) upd_fast_body<NKF, 2, false, true, UPD_KIND_REC>(fz.upd, e, tid, 256, ured, ubc, ust);
+        else upd_fast_body<NKF, 2, false, true>(fz.upd, e, tid, 256, ured, ubc, ust);
+        if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamps[4] = wall_clock64(); }
+      }
+    }
   }
 }
+
+template <int NH, int FQ>
+constexpr int w64_fuse_nk() { return ((8 * FQ * 64 + 64 + (NH - 1) * 4160 + 130) / 4 + 255) / 256; }

@@ -45,6 +45,7 @@ struct mile_sampler {
   // workspace
   int E_cap = 0, S_cap = 0;
   float *slabs = nullptr, *llpart = nullptr, *dK = nullptr, *lold = nullptr;
+  int32_t *arrive = nullptr;            // [E_cap] arrival tickets of the fused integrator epilogue (k_grad_w64 SPLIT)
   float *ev_X = nullptr, *ev_Xp = nullptr; void *ev_y = nullptr; int ev_cap = 0;   // evaluation (test) set staging
   float *alt_x = nullptr, *alt_u = nullptr, *alt_g = nullptr, *alt_logp = nullptr;   // ping-pong state of mile_tune
   int grad_kernel = MILE_GRAD_AUTO;
@@ -288,6 +289,8 @@ static void free_ws(mile_sampler *s) {
   s->alt_x = s->alt_u = s->alt_g = s->alt_logp = nullptr;
   if (s->tune_info) (void)hipFree(s->tune_info);
   s->tune_info = nullptr;
+  if (s->arrive) (void)hipFree(s->arrive);
+  s->arrive = nullptr;
   s->slabs = s->llpart = s->dK = s->lold = nullptr;
   s->E_cap = s->S_cap = 0;
 }
@@ -390,6 +393,8 @@ int32_t mile_reserve(mile_sampler *s, int32_t E) {
   HIP_TRY(hipMalloc(&s->alt_u, (size_t)E * s->ds.d * 4));
   HIP_TRY(hipMalloc(&s->alt_g, (size_t)E * s->ds.d * 4));
   HIP_TRY(hipMalloc(&s->alt_logp, (size_t)E * 4));
+  HIP_TRY(hipMalloc(&s->arrive, ((size_t)E * 4 + 15) / 16 * 16));
+  HIP_TRY(hipMemset(s->arrive, 0, ((size_t)E * 4 + 15) / 16 * 16));
   s->E_cap = E;
   s->S_cap = S;
   return MILE_OK;
@@ -428,12 +433,20 @@ static void launch_update_al(const UpdParams &u, int E, int nk, hipStream_t st) 
   // half the chip (d = 8834: 2208 quads, nk = 3 -> 768 threads instead of 1024)
   const int nqf = u.d >> 2;
   const int nt = std::min(UPD_NT, ((nqf + nk - 1) / nk + 63) / 64 * 64);
+  const int kind = SDC ? -1 : upd_kind(u);
+#define MILE_UPD_CASE(NK_)                                                                       \
+  if constexpr (!SDC) {                                                                          \
+    if (kind == UPD_KIND_MID) { k_update_fast<NK_, AL, SDC, UPD_KIND_MID><<<E, nt, 0, st>>>(u); break; } \
+    if (kind == UPD_KIND_REC) { k_update_fast<NK_, AL, SDC, UPD_KIND_REC><<<E, nt, 0, st>>>(u); break; } \
+  }                                                                                              \
+  k_update_fast<NK_, AL, SDC><<<E, nt, 0, st>>>(u); break;
   switch (nk) {
-    case 1: k_update_fast<1, AL, SDC><<<E, nt, 0, st>>>(u); break;
-    case 2: k_update_fast<2, AL, SDC><<<E, nt, 0, st>>>(u); break;
-    case 3: k_update_fast<3, AL, SDC><<<E, nt, 0, st>>>(u); break;
-    default: k_update_fast<4, AL, SDC><<<E, nt, 0, st>>>(u); break;
+    case 1: MILE_UPD_CASE(1)
+    case 2: MILE_UPD_CASE(2)
+    case 3: MILE_UPD_CASE(3)
+    default: MILE_UPD_CASE(4)
   }
+#undef MILE_UPD_CASE
 }
 
 static void launch_update(const UpdParams &u, int E, hipStream_t st) {
@@ -460,8 +473,12 @@ static void launch_update(const UpdParams &u, int E, hipStream_t st) {
   }
 }
 
+// The F > 8 split kernels live in their own translation unit, built WITHOUT -amdgpu-mfma-vgpr-form: with that option
+// hipcc 7.2's 'AMDGPU Rewrite AGPR-Copy-MFMA' pass crashes on the heavily spilling k_grad_w64<3,2,true> (mile_amd/_build.py).
+hipError_t mile_launch_w64_split_fq2(int nh, const GradParams &gp, int E, hipStream_t st);
+
 template <int NH, int FQ, bool SPLIT = false>
-static hipError_t launch_w64(const GradParams &gp, int E, hipStream_t st) {
+static hipError_t launch_w64(const GradParams &gp, const W64Fuse &fz, int E, hipStream_t st) {
   using LY = W64Layout<NH, FQ, SPLIT>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -469,8 +486,28 @@ static hipError_t launch_w64(const GradParams &gp, int E, hipStream_t st) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  k_grad_w64<NH, FQ, SPLIT><<<dim3(gp.S, E), 256, LY::BYTES, st>>>(gp);
+  if constexpr (W64FuseArg<FQ, SPLIT>::FUSABLE) {
+    k_grad_w64<NH, FQ, SPLIT><<<dim3(gp.S, E), 256, LY::BYTES, st>>>(gp, fz);
+  } else {
+    if (fz.enabled) return hipErrorInvalidValue;
+    k_grad_w64<NH, FQ, SPLIT><<<dim3(gp.S, E), 256, LY::BYTES, st>>>(gp, W64NoFuse{0});
+  }
   return hipGetLastError();
+}
+
+// Can the update that follows this gradient run as the grad launch's epilogue (k_grad_w64 SPLIT, W64Fuse)?
+// 8-byte aligned rows everywhere (the epilogue is the AL = 2 form), no preconditioner, d within its register cache.
+static bool fuse_ok(const mile_sampler *s, int kernel, const UpdParams &u) {
+  if (!MILE_W64_EPILOGUE_ON || kernel != MILE_GRAD_MFMA_W64_BF16X3 || getenv("MILE_NO_FUSE")) return false;
+  if (u.sdc || (u.d & 1)) return false;
+  const int nh = s->spec.n_layers - 1, fq = s->Fp / 8;
+  if (fq != 1) return false;                       // the F > 8 kernels are built without the epilogue (mile_grad_w64.h)
+  const int nk = nh == 2 ? w64_fuse_nk<2, 1>() : w64_fuse_nk<3, 1>();
+  if ((u.d >> 2) > 256 * nk) return false;
+  const void *ptrs[] = {u.x, u.u, u.g, u.zA, u.zB, u.out_sample, u.x_in, u.u_in, u.g_in, u.t_avg, u.bk_x, u.bk_u, u.bk_g};
+  for (const void *q : ptrs)
+    if (q && ptr_align(q) < 2) return false;
+  return true;
 }
 
 template <int NH>
@@ -769,7 +806,7 @@ static int launch_grad_gemm(mile_sampler *s, const GradParams &gp, int E, hipStr
   return MILE_OK;
 }
 
-static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t st) {
+static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t st, const UpdParams *fused_update = nullptr) {
   if (!s->X) return fail(MILE_ERR_STATE, "no data: call mile_set_data first");
   const int kernel = resolved_kernel(s);
   const int S = choose_S(s, E, kernel);
@@ -783,6 +820,7 @@ static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t s
   { const char *dv = getenv("MILE_DEBUG"); gp.dbg = dv ? atoi(dv) : 0; }
   gp.dbg_buf = nullptr;
   if ((gp.dbg & 16) && !s->dbg_buf) HIP_TRY(hipMalloc(&s->dbg_buf, 64));
+  if ((gp.dbg & 32) && !s->dbg_buf) HIP_TRY(hipMalloc(&s->dbg_buf, (size_t)s->E_cap * s->S_cap * 128));
   gp.dbg_buf = s->dbg_buf;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (s->timing) {
@@ -797,23 +835,27 @@ static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t s
     s->ev_used += 2;
     HIP_TRY(hipEventRecord(e0, st));
   }
+  W64Fuse fz{};
+  if (fused_update) {
+    if (kernel != MILE_GRAD_MFMA_W64_BF16X3) return fail(MILE_ERR_STATE, "fused update needs the mfma_w64_bf16x3 grad kernel");
+    fz.upd = *fused_update; fz.arrive = s->arrive; fz.enabled = 1; fz.kind = upd_kind(*fused_update);
+  }
   if (kernel == MILE_GRAD_MFMA_W64) {
     const int nh = s->spec.n_layers - 1, fq = s->Fp / 8;
     hipError_t e = hipErrorInvalidValue;
-    if (nh == 1 && fq == 1) e = launch_w64<1, 1>(gp, E, st);
-    else if (nh == 2 && fq == 1) e = launch_w64<2, 1>(gp, E, st);
-    else if (nh == 3 && fq == 1) e = launch_w64<3, 1>(gp, E, st);
-    else if (nh == 1 && fq == 2) e = launch_w64<1, 2>(gp, E, st);
-    else if (nh == 2 && fq == 2) e = launch_w64<2, 2>(gp, E, st);
-    else if (nh == 3 && fq == 2) e = launch_w64<3, 2>(gp, E, st);
+    if (nh == 1 && fq == 1) e = launch_w64<1, 1>(gp, fz, E, st);
+    else if (nh == 2 && fq == 1) e = launch_w64<2, 1>(gp, fz, E, st);
+    else if (nh == 3 && fq == 1) e = launch_w64<3, 1>(gp, fz, E, st);
+    else if (nh == 1 && fq == 2) e = launch_w64<1, 2>(gp, fz, E, st);
+    else if (nh == 2 && fq == 2) e = launch_w64<2, 2>(gp, fz, E, st);
+    else if (nh == 3 && fq == 2) e = launch_w64<3, 2>(gp, fz, E, st);
     HIP_TRY(e);
   } else if (kernel == MILE_GRAD_MFMA_W64_BF16X3) {
     const int nh = s->spec.n_layers - 1, fq = s->Fp / 8;
     hipError_t e = hipErrorInvalidValue;
-    if (nh == 2 && fq == 1) e = launch_w64<2, 1, true>(gp, E, st);
-    else if (nh == 3 && fq == 1) e = launch_w64<3, 1, true>(gp, E, st);
-    else if (nh == 2 && fq == 2) e = launch_w64<2, 2, true>(gp, E, st);
-    else if (nh == 3 && fq == 2) e = launch_w64<3, 2, true>(gp, E, st);
+    if (nh == 2 && fq == 1) e = launch_w64<2, 1, true>(gp, fz, E, st);
+    else if (nh == 3 && fq == 1) e = launch_w64<3, 1, true>(gp, fz, E, st);
+    else if (fq == 2 && !fz.enabled) e = mile_launch_w64_split_fq2(nh, gp, E, st);   // mile_w64_fq2.hip
     HIP_TRY(e);
   } else if (kernel == MILE_GRAD_LENET_F32) {
     const int rc = run_lenet(s, theta, E, gp.X, gp.y, s->N, gp.slabs, gp.dp, gp.llpart, nullptr, 0, st);
@@ -835,6 +877,34 @@ static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t s
     HIP_TRY(hipGetLastError());
   }
   if (s->timing) HIP_TRY(hipEventRecord(e1, st));
+  if ((gp.dbg & 32) && is_w64(kernel)) {   // dev: phase timestamps of the w64 kernels (100 MHz wall clock -> us)
+    std::vector<long long> hb((size_t)E * S * 16);
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(hb.data(), s->dbg_buf, hb.size() * 8, hipMemcpyDeviceToHost));
+    long long t00 = hb[0], tend = 0;
+    for (int w = 0; w < E * S; ++w) { t00 = std::min(t00, hb[w * 16]); tend = std::max({tend, hb[w * 16 + 2], hb[w * 16 + 4]}); }
+    double a[4] = {0, 0, 0, 0}, mx[4] = {0, 0, 0, 0}, ep[4] = {0, 0, 0, 0}, sub[4] = {0, 0, 0, 0}; int nl = 0;
+    for (int w = 0; w < E * S; ++w) {
+      const long long *q = &hb[w * 16];
+      const double v0 = (q[1] - q[0]) * 0.01, v1 = (q[2] - q[1]) * 0.01;
+      a[0] += v0; a[1] += v1; mx[0] = std::max(mx[0], v0); mx[1] = std::max(mx[1], v1);
+      if (q[4]) { const double v2 = (q[3] - q[2]) * 0.01, v3 = (q[4] - q[3]) * 0.01; a[2] += v2; a[3] += v3; mx[2] = std::max(mx[2], v2); mx[3] = std::max(mx[3], v3); ++nl;
+        ep[0] += (q[5] - q[3]) * 0.01; ep[1] += (q[6] - q[5]) * 0.01; ep[2] += (q[7] - q[6]) * 0.01; ep[3] += (q[4] - q[7]) * 0.01;
+        sub[0] += (q[8] - q[5]) * 0.01; sub[1] += (q[9] - q[8]) * 0.01; sub[2] += (q[10] - q[9]) * 0.01; sub[3] += (q[6] - q[10]) * 0.01; }
+    }
+    fprintf(stderr, "w64 phases (us, mean/max over %d WGs): main %.1f/%.1f reduce+store %.1f/%.1f | last arrivers (%d): drain+ticket %.1f/%.1f epilogue %.1f/%.1f | first start -> last end %.1f\n",
+            E * S, a[0] / (E * S), mx[0], a[1] / (E * S), mx[1], nl, nl ? a[2] / nl : 0.0, mx[2], nl ? a[3] / nl : 0.0, mx[3], (tend - t00) * 0.01);
+    if (nl) fprintf(stderr, "    epilogue: loads %.1f  noise+sums+reduce %.1f  chain %.1f  pass2+stores %.1f   [sums: quads %.1f tail %.1f wave_sum %.1f lds+barrier %.1f]\n", ep[0] / nl, ep[1] / nl, ep[2] / nl, ep[3] / nl, sub[0] / nl, sub[1] / nl, sub[2] / nl, sub[3] / nl);
+  }
+  return MILE_OK;
+}
+
+// gradient at `theta`, then the update `u` that consumes it: one launch when the update can be the grad kernel's epilogue
+static int grad_then_update(mile_sampler *s, const float *theta, int E, const UpdParams &u, bool fused, hipStream_t st) {
+  if (fused) return launch_grad(s, theta, E, st, &u);
+  const int rc = launch_grad(s, theta, E, st);
+  if (rc) return rc;
+  launch_update(u, E, st);
   return MILE_OK;
 }
 
@@ -1081,6 +1151,11 @@ int32_t mile_step(mile_sampler *s, mile_state *state, const mile_step_args *a, v
   const size_t Ed = (size_t)E * d;
   auto noise_at = [&](int i, int k) -> const float * { return a->noise ? a->noise + ((size_t)i * 2 + k) * Ed : nullptr; };
 
+  // two launches per step when the updates can run as the grad kernel's epilogue (k_grad_w64 SPLIT), else four
+  UpdParams probe = up;
+  probe.zA = a->noise; probe.zB = a->noise; probe.out_sample = a->out_samples;
+  const bool fused = fuse_ok(s, kernel, probe);
+  if (fused) HIP_TRY(hipMemsetAsync(s->arrive, 0, ((size_t)E * 4 + 15) / 16 * 16, st));   // tickets re-zeroed every call
   int kept = 0;
   for (int i = 0; i < a->n_steps; ++i) {
     const int64_t gstep = a->step_offset + i;
@@ -1091,17 +1166,14 @@ int32_t mile_step(mile_sampler *s, mile_state *state, const mile_step_args *a, v
       u.coef_b2 = b1; u.coef_a = 0.5f;
       launch_update(u, E, st);
     }
-    int rc = launch_grad(s, state->position, E, st);
-    if (rc) return rc;
-    {  // B(1 - 2 b1) . A(1/2)
+    {  // grad . B(1 - 2 b1) . A(1/2)
       UpdParams u = up;
       u.flags = UPD_FROM_SLABS | UPD_B1 | UPD_A | UPD_NO_G;
       u.coef_b1 = b2; u.coef_a = 0.5f;
-      launch_update(u, E, st);
+      const int rc = grad_then_update(s, state->position, E, u, fused, st);
+      if (rc) return rc;
     }
-    rc = launch_grad(s, state->position, E, st);
-    if (rc) return rc;
-    {  // B(b1) . O(z2) . record  [ . O(z1') . B(b1) . A(1/2) of the next step ]
+    {  // grad . B(b1) . O(z2) . record  [ . O(z1') . B(b1) . A(1/2) of the next step ]
       UpdParams u = up;
       const bool last = (i == a->n_steps - 1);
       u.flags = UPD_FROM_SLABS | UPD_B1 | UPD_OA | UPD_RECORD;
@@ -1117,7 +1189,8 @@ int32_t mile_step(mile_sampler *s, mile_state *state, const mile_step_args *a, v
         u.out_sample = a->out_samples + (size_t)kept * Ed;
         ++kept;
       }
-      launch_update(u, E, st);
+      const int rc = grad_then_update(s, state->position, E, u, fused, st);
+      if (rc) return rc;
     }
   }
   HIP_TRY(hipGetLastError());
@@ -1223,6 +1296,11 @@ int32_t mile_tune(mile_sampler *s, mile_state *state, const mile_tune_args *a, v
     return MILE_OK;
   }
 
+  UpdParams probe = up;
+  probe.x = A.x; probe.u = A.u; probe.g = A.g; probe.x_in = B.x; probe.u_in = B.u; probe.g_in = B.g;
+  probe.zA = a->noise; probe.t_avg = a->stream_average;
+  const bool fused = fuse_ok(s, resolved_kernel(s), probe);
+  if (fused) HIP_TRY(hipMemsetAsync(s->arrive, 0, ((size_t)E * 4 + 15) / 16 * 16, st));
   for (int i = 0; i < a->n_steps; ++i) {
     const Buf &cur = (i & 1) ? B : A, &nxt = (i & 1) ? A : B;
     const int64_t gstep = a->step_offset + i;
@@ -1235,17 +1313,14 @@ int32_t mile_tune(mile_sampler *s, mile_state *state, const mile_tune_args *a, v
       u.coef_b2 = b1; u.coef_a = 0.5f;
       launch_update(u, E, st);
     }
-    int rc = launch_grad(s, nxt.x, E, st);
-    if (rc) return rc;
     {
       UpdParams u = up;
       set_state(u, nxt);
       u.flags = UPD_FROM_SLABS | UPD_B1 | UPD_A | UPD_NO_G;
       u.coef_b1 = b2; u.coef_a = 0.5f;
-      launch_update(u, E, st);
+      const int rc = grad_then_update(s, nxt.x, E, u, fused, st);
+      if (rc) return rc;
     }
-    rc = launch_grad(s, nxt.x, E, st);
-    if (rc) return rc;
     {  // B(b1) . O(z2) . record + tuner (step-size predictor, handle_nans, streaming averages)
       UpdParams u = up;
       set_state(u, nxt);
@@ -1260,7 +1335,8 @@ int32_t mile_tune(mile_sampler *s, mile_state *state, const mile_tune_args *a, v
       u.t_var = target_var(sp);
       u.t_trust = a->trust_in_estimate; u.t_decay = a->decay_rate;
       if (a->out_info) u.out_info = a->out_info + (size_t)i * E * 3;
-      launch_update(u, E, st);
+      const int rc = grad_then_update(s, nxt.x, E, u, fused, st);
+      if (rc) return rc;
     }
   }
   if (a->n_steps & 1) {   // the final state sits in the library's buffer

@@ -13,6 +13,8 @@
 //   pass 2: writes u' = c . {u, e, zA, zB}, the thinned sample, and x' = x + eps a u' s.
 // A whole "end of step i + start of step i+1" sequence is therefore one launch.
 #pragma once
+#include <cstdlib>
+
 #include "mile_device.h"
 
 enum : int32_t {
@@ -109,7 +111,7 @@ struct Chain {
 // CACHED: every thread keeps its <= UPD_QMAX quads of (x, u, g~, zA, zB) in registers between
 // pass 1 and pass 2, so state is read once, noise is generated once and written once.
 template <bool CACHED>
-__global__ __launch_bounds__(UPD_NT) void k_update(const UpdParams p) {
+static __global__ __launch_bounds__(UPD_NT) void k_update(const UpdParams p) {
   __shared__ float red[UPD_NW][UPD_NSUM + 1];
   __shared__ float tot[UPD_NSUM + 1];
   const int tid = threadIdx.x, e = blockIdx.x, d = p.d;
@@ -321,34 +323,61 @@ __device__ __forceinline__ void st4(float *q, const f32x4 v) {
   }
 }
 
-template <int NK, int AL, bool SDC>
-__global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
-  __shared__ float red[UPD_NW][UPD_NSUM + 1];
-  // launched with the fewest waves that still give NK quads per thread (nt = blockDim.x <= UPD_NT, a multiple of 64): the
-  // kernel is VALU-bound on half the chip (E workgroups), so idle padded lanes cost real time (d = 8834: 768 threads, not 1024)
-  const int tid = threadIdx.x, e = blockIdx.x, d = p.d, nt = blockDim.x;
+// Slab / llpart reads.  COH = the update runs as the EPILOGUE of the grad launch that produced the slabs (last-arriving
+// workgroup of the particle, mile_grad_w64.h): every byte another workgroup of this launch wrote is read with an sc1 load
+// (L1 bypassed; the producer stored it sc1 and drained) -- /opt/skills/guides cdna_hip_programming.md section 6 Guideline 16,
+// the counter form of the hand-off.  Slab rows are 16-byte aligned whatever AL says (dp % 4 == 0).
+typedef uint32_t upd_u32x4 __attribute__((ext_vector_type(4)));
+template <int AL, bool COH>
+__device__ __forceinline__ f32x4 ld4_slab(const float *row, __amdgpu_buffer_rsrc_t rs, int float_off) {
+  if constexpr (COH) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, float_off * 4, 0, 16));   // aux 16 = sc1
+  } else {
+    return ld4<AL>(row + float_off);
+  }
+}
+template <bool COH>
+__device__ __forceinline__ float ld1_shared(const float *q) {
+  if constexpr (COH) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *q;
+}
+
+// The body of k_update_fast for particle e, run by `nt` threads (a multiple of 64, nt * NK >= d / 4) with thread index tid;
+// red / bc: LDS scratch of the caller ([nt / 64][UPD_NSUM + 1] and [8] floats).
+// CF >= 0: the launch kind is known at compile time -- the flag word is the constant CF and the prior is Normal -- so every
+// flag test folds and the per-element code is branch-free (the steady state of a sampling run is two kinds, UPD_KIND_MID and
+// UPD_KIND_REC).  CF < 0: flags and prior kind are read from p at run time (first / last launches of a call, tuner, Laplace
+// prior, step-O refresh).
+#define UPD_KIND_MID (UPD_FROM_SLABS | UPD_B1 | UPD_A | UPD_NO_G)
+#define UPD_KIND_REC (UPD_FROM_SLABS | UPD_B1 | UPD_OA | UPD_RECORD | UPD_OB | UPD_B2 | UPD_A | UPD_NO_G)
+template <int NK, int AL, bool SDC, bool COH, int CF = -1>
+__device__ __forceinline__ void upd_fast_body(const UpdParams &p, const int e, const int tid, const int nt,
+                                              float (*red)[UPD_NSUM + 1], float *bc, long long *stamps = nullptr) {
+  const int d = p.d;
+  const int flags = CF >= 0 ? CF : p.flags;
   const size_t base = (size_t)e * d;
   const int nqf = d >> 2;            // full quads
   const int ntail = d & 3;           // leftover elements, handled by threads 0..ntail-1
-  const bool from_slabs = p.flags & UPD_FROM_SLABS;
-  const bool useA = p.flags & UPD_OA, useB = p.flags & UPD_OB;
+  const bool from_slabs = flags & UPD_FROM_SLABS;
+  const bool useA = flags & UPD_OA, useB = flags & UPD_OB;
   const bool explA = useA && p.zA, explB = useB && p.zB;
   const uint32_t pid = p.pids ? (uint32_t)p.pids[e] : (uint32_t)e;
   const float *sl = p.slabs + (size_t)e * p.S * p.dp;
+  const __amdgpu_buffer_rsrc_t sl_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sl), 0, p.S * p.dp * 4, 0x00020000);
   const float *xin = p.x_in ? p.x_in : p.x, *uin = p.u_in ? p.u_in : p.u, *gin = p.g_in ? p.g_in : p.g;
-  const bool tune = p.flags & UPD_TUNE;
-  const bool store_g = from_slabs && !(p.flags & UPD_NO_G);
+  const bool tune = flags & UPD_TUNE;
+  const bool store_g = from_slabs && !(flags & UPD_NO_G);
   const float ips = 1.0f / p.prior_scale;
-  const bool normal = p.prior == MILE_PRIOR_NORMAL;
+  const bool normal = CF >= 0 ? true : p.prior == MILE_PRIOR_NORMAL;
 
   // per-particle scalars, fetched up front so their latency hides under the vector loads
   const float eps_in = p.eps[e], L_in = p.L[e];
-  const float dk_in = (p.flags & UPD_START) ? 0.0f : p.dK[e];
-  const float lold_in = (p.flags & UPD_START) ? 0.0f : p.lold[e];
+  const float dk_in = (flags & UPD_START) ? 0.0f : p.dK[e];
+  const float lold_in = (flags & UPD_START) ? 0.0f : p.lold[e];
   const float logp_in = from_slabs ? 0.0f : (p.logp_in ? p.logp_in : p.logp)[e];
   float ll_in = 0.0f;
   if (from_slabs)
-    for (int s = 0; s < p.S; ++s) ll_in += p.llpart[(size_t)e * p.S + s];
+    for (int s = 0; s < p.S; ++s) ll_in += ld1_shared<COH>(p.llpart + (size_t)e * p.S + s);
 
   f32x4 cx[NK], cu[NK], cg[NK], ca[NK], cb[NK], csd[SDC ? NK : 1];
   // ---- pass 1: loads -----------------------------------------------------------------
@@ -360,8 +389,9 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
     cx[k] = ld4<AL>(xin + o);
     cu[k] = ld4<AL>(uin + o);
     if (from_slabs) {
-      f32x4 g = ld4<AL>(sl + (o - base));
-      for (int s = 1; s < p.S; ++s) g += ld4<AL>(sl + (size_t)s * p.dp + (o - base));
+      const int so = (int)(o - base);
+      f32x4 g = ld4_slab<AL, COH>(sl, sl_rs, so);
+      for (int s = 1; s < p.S; ++s) g += ld4_slab<AL, COH>(sl, sl_rs, s * p.dp + so);
       cg[k] = g;
     } else {
       cg[k] = ld4<AL>(gin + o);
@@ -377,12 +407,13 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
   if (ntail) {
     const size_t tc = has_tail ? to : base;
     tx = xin[tc]; tu = uin[tc];
-    if (from_slabs) { tg = 0.0f; for (int s = 0; s < p.S; ++s) tg += sl[(size_t)s * p.dp + (tc - base)]; }
+    if (from_slabs) { tg = 0.0f; for (int s = 0; s < p.S; ++s) tg += ld1_shared<COH>(sl + (size_t)s * p.dp + (tc - base)); }
     else tg = gin[tc];
     if (SDC) tsd = p.sdc[tc];
     if (explA) ta = p.zA[tc];
     if (explB) tb = p.zB[tc];
   }
+  if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamps[0] = wall_clock64(); }   // dev: loads landed
   // ---- pass 1: noise + sums ------------------------------------------------------------
   float sm[UPD_NSUM];
 #pragma unroll
@@ -418,6 +449,7 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
       for (int m = 0; m < 4; ++m) cg[k][m] *= csd[k][m];   // keep g~ = g*s for pass 2
     }
   }
+  if (stamps) stamps[3] = wall_clock64();
   if (ntail) {
     f32x4 za = {0, 0, 0, 0}, zb = {0, 0, 0, 0};
     if (useA && !p.zA) za = philox_normal4(nqf, pid, p.stepA, p.stageA, p.seed);
@@ -441,15 +473,17 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
     sm[6] = fmaf(ui, tb, sm[6]); sm[7] = fmaf(gs, tb, sm[7]); sm[8] = fmaf(tb, tb, sm[8]);
     sm[9] = fmaf(ta, tb, sm[9]);
   }
+  if (stamps) stamps[4] = wall_clock64();
 #pragma unroll
   for (int k = 0; k < UPD_NSUM; ++k) sm[k] = wave_sum(sm[k]);
+  if (stamps) stamps[5] = wall_clock64();
   if ((tid & 63) == 0)
 #pragma unroll
     for (int k = 0; k < UPD_NSUM; ++k) red[tid >> 6][k] = sm[k];
   __syncthreads();
+  if (stamps) stamps[1] = wall_clock64();                                                          // dev: sums reduced
 
   // ---- scalar chain: wave 0 only, coefficients broadcast through LDS ------------------------
-  __shared__ float bc[8];
   if (tid < 64) {
   float S[UPD_NSUM];
   {
@@ -483,12 +517,12 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
     for (int b = 0; b < 4; ++b)
       if (b < a) ch.M[a][b] = ch.M[b][a];
   ch.c[0] = 1.0f; ch.c[1] = ch.c[2] = ch.c[3] = 0.0f;
-  float dk = (p.flags & UPD_START) ? 0.0f : dk_in;
-  float lold = (p.flags & UPD_START) ? logp_now : lold_in;
-  if (p.flags & UPD_B1) dk += ch.B(eps, p.coef_b1, gn, d);
-  if (p.flags & UPD_OA) ch.O(2, p.hA * eps, L, d);
+  float dk = (flags & UPD_START) ? 0.0f : dk_in;
+  float lold = (flags & UPD_START) ? logp_now : lold_in;
+  if (flags & UPD_B1) dk += ch.B(eps, p.coef_b1, gn, d);
+  if (flags & UPD_OA) ch.O(2, p.hA * eps, L, d);
   float info_dk = 0.0f, info_de = 0.0f;
-  if (p.flags & UPD_RECORD) {
+  if (flags & UPD_RECORD) {
     info_dk = dk;
     info_de = dk - (logp_now - lold);
     dk = 0.0f;
@@ -523,13 +557,13 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
       p.t_W[e] = t_Wold + t_wgt;
     }
   }
-  if (p.flags & UPD_OB) ch.O(3, p.hB * eps, L, d);
-  if (p.flags & UPD_B2) dk += ch.B(eps, p.coef_b2, gn, d);
+  if (flags & UPD_OB) ch.O(3, p.hB * eps, L, d);
+  if (flags & UPD_B2) dk += ch.B(eps, p.coef_b2, gn, d);
   if (tid == 0) {
     p.dK[e] = dk;
     p.lold[e] = lold;
     if (from_slabs || tune) p.logp[e] = logp_now;
-    if ((p.flags & UPD_RECORD) && p.out_info) {
+    if ((flags & UPD_RECORD) && p.out_info) {
       p.out_info[3 * e + 0] = logp_now;
       p.out_info[3 * e + 1] = info_dk;
       p.out_info[3 * e + 2] = info_de;
@@ -539,9 +573,10 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
   }
   }
   __syncthreads();
+  if (stamps) stamps[2] = wall_clock64();                                                          // dev: chain done
   // ---- pass 2 (from registers) ------------------------------------------------------------
-  const bool any_op = p.flags & (UPD_B1 | UPD_OA | UPD_OB | UPD_B2);
-  const bool doA = p.flags & UPD_A;
+  const bool any_op = flags & (UPD_B1 | UPD_OA | UPD_OB | UPD_B2);
+  const bool doA = flags & UPD_A;
   const float c0 = bc[0], c1 = bc[1], c2 = bc[2], c3 = bc[3], ea = bc[4];
   const bool t_ok = bc[5] != 0.0f;
   const float t_Wold = bc[6], t_wgt = bc[7];
@@ -599,9 +634,26 @@ __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
   }
 }
 
+template <int NK, int AL, bool SDC, int CF = -1>
+static __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
+  __shared__ float red[UPD_NW][UPD_NSUM + 1];
+  __shared__ float bc[8];
+  // launched with the fewest waves that still give NK quads per thread (nt = blockDim.x <= UPD_NT, a multiple of 64): the
+  // kernel is VALU-bound on half the chip (E workgroups), so idle padded lanes cost real time (d = 8834: 768 threads, not 1024)
+  upd_fast_body<NK, AL, SDC, false, CF>(p, blockIdx.x, threadIdx.x, blockDim.x, red, bc);
+}
+
+// which compile-time kind a launch is (else -1): steady-state flag words with a Normal prior, no tuner, no preconditioner
+static inline int upd_kind(const UpdParams &u) {
+  if (u.prior != MILE_PRIOR_NORMAL || u.sdc || getenv("MILE_NO_UPD_KIND")) return -1;
+  if (u.flags == UPD_KIND_MID) return UPD_KIND_MID;
+  if (u.flags == UPD_KIND_REC) return UPD_KIND_REC;
+  return -1;
+}
+
 #define AUX_NT 256
 // g = sum_s slab + grad log prior;  logp = sum_s llpart + log prior.   (mile_logpost_grad)
-__global__ __launch_bounds__(AUX_NT) void k_finalize(int d, int dp, int S, int prior, float loc, float scale,
+static __global__ __launch_bounds__(AUX_NT) void k_finalize(int d, int dp, int S, int prior, float loc, float scale,
                                                      const float *theta, const float *slabs,
                                                      const float *llpart, float *grad, float *logp) {
   __shared__ float red[AUX_NT / 64];
@@ -631,7 +683,7 @@ __global__ __launch_bounds__(AUX_NT) void k_finalize(int d, int dp, int S, int p
 }
 
 // momentum = z / |z|  (generate_unit_vector of blackjax.mcmc.mclmc.init, A.1)
-__global__ __launch_bounds__(AUX_NT) void k_init_momentum(int d, const float *z, uint64_t seed,
+static __global__ __launch_bounds__(AUX_NT) void k_init_momentum(int d, const float *z, uint64_t seed,
                                                           const int32_t *pids, float *u) {
   __shared__ float red[AUX_NT / 64];
   const int tid = threadIdx.x, e = blockIdx.x;
@@ -661,7 +713,7 @@ __global__ __launch_bounds__(AUX_NT) void k_init_momentum(int d, const float *z,
   for (int i = tid; i < d; i += AUX_NT) u[base + i] *= inv;
 }
 
-__global__ __launch_bounds__(AUX_NT) void k_debug_noise(int d, uint64_t seed, const int32_t *pids,
+static __global__ __launch_bounds__(AUX_NT) void k_debug_noise(int d, uint64_t seed, const int32_t *pids,
                                                         uint32_t step, uint32_t stage, float *out) {
   const int tid = threadIdx.x, e = blockIdx.x;
   const uint32_t pid = pids ? (uint32_t)pids[e] : (uint32_t)e;
@@ -686,7 +738,7 @@ struct TunePostParams {
   float t_mask, t_var, t_trust, t_decay;
 };
 
-__global__ __launch_bounds__(AUX_NT) void k_tune_post(const TunePostParams p) {
+static __global__ __launch_bounds__(AUX_NT) void k_tune_post(const TunePostParams p) {
   __shared__ float red[AUX_NT / 64];
   __shared__ float bc[4];
   const int tid = threadIdx.x, e = blockIdx.x, d = p.d;
