@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MILE_ABI_VERSION 2
+#define MILE_ABI_VERSION 3
 #define MILE_MAX_LAYERS 16
 
 typedef enum mile_status {
@@ -67,8 +67,12 @@ typedef enum mile_grad_kernel {
   MILE_GRAD_MFMA_W128_BF16 = 3,   /* ReLU regression, 1-3 hidden layers of width 128, bf16 MFMA */
   MILE_GRAD_GEMM_F32 = 4,         /* any FCN, fp32: rocBLAS strided-batched SGEMMs + elementwise HIP kernels (wide nets) */
   MILE_GRAD_LENET_F32 = 5,        /* MILE_MODEL_LENET only: im2col + the same SGEMMs, pooling / col2im HIP kernels */
-  MILE_GRAD_MFMA_W64_BF16X3 = 6   /* as MFMA_W64 with 2-3 hidden layers; the hidden->hidden forward / dH / dW products run as six
+  MILE_GRAD_MFMA_W64_BF16X3 = 6,  /* as MFMA_W64 with 2-3 hidden layers; the hidden->hidden forward / dH / dW products run as six
                                      bf16 MFMA products of exact three-term bf16 splits of the fp32 operands (fp32-faithful) */
+  MILE_GRAD_MFMA_WIDE_BF16X3 = 7, /* any FCN, layer-wise: hand-written batched MFMA GEMMs (k_mm3) with the same fp32-faithful
+                                     three-term bf16 products, bias / activation / activation-derivative fused into their
+                                     epilogues; what AUTO picks for wide nets (hidden width >= 96: B4's 4 x 256 softmax net) */
+  MILE_GRAD_MFMA_WIDE_BF16 = 8    /* the same kernels with bf16-ROUNDED operands (one product instead of six); explicit only */
 } mile_grad_kernel;
 /* Which network: the FCN (src/models/tabular/fcn.py:16-28) or LeNet (src/models/images/cnns.py:10-66). */
 typedef enum mile_model { MILE_MODEL_FCN = 0, MILE_MODEL_LENET = 1 } mile_model;

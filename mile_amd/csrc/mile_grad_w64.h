@@ -71,6 +71,9 @@ struct W64FuseArg {
 };
 
 #define W64_RS 68  // row stride (floats) of every padded LDS image
+#ifndef W64_OVERLAP
+#define W64_OVERLAP 1   // SPLIT main loop: form the next backward layer's dZ (mask + split) inside the dW MFMA groups
+#endif
 
 __device__ __forceinline__ int tfeat(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 __device__ __forceinline__ int nrow(int s, int h) { return 8 * (s >> 2) + 4 * h + (s & 3); }

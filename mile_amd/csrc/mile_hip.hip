@@ -17,6 +17,7 @@
 #include "mile_grad_w64.h"
 #include "mile_grad_w128b.h"
 #include "mile_grad_gemm.h"
+#include "mile_mm3.h"
 #include "mile_lenet.h"
 #include "mile_predict.h"
 #include "mile_update.h"
@@ -58,6 +59,10 @@ struct mile_sampler {
   int gemm_ones_n = 0;
   size_t gemm_ws_floats = 0;
   int gemm_R = 0, gemm_E = 0;
+  // layer-wise MFMA path (MILE_GRAD_MFMA_WIDE_*): activation workspace (zero-initialised: padding columns stay 0) and
+  // the pre-split weight term planes
+  float *wide_ws = nullptr; size_t wide_ws_floats = 0; int wide_R = 0, wide_E = 0;
+  void *wide_wt = nullptr; size_t wide_wt_bytes = 0;
   // timing of grad launches
   bool timing = false;
   std::vector<hipEvent_t> ev;
@@ -137,7 +142,8 @@ static int resolved_kernel(const mile_sampler *s) {
   if (s->grad_kernel == MILE_GRAD_AUTO) {
     if (w64x3_supported(s->spec)) return MILE_GRAD_MFMA_W64_BF16X3;   // fp32-faithful and never slower than MFMA_W64
     if (w64_supported(s->spec)) return MILE_GRAD_MFMA_W64;
-    return gemm_preferred(s->spec) && rocblas_load() ? MILE_GRAD_GEMM_F32 : MILE_GRAD_GENERIC;
+    // wide nets: the hand-written layer-wise MFMA GEMMs (fp32-faithful); rocBLAS (GEMM_F32) is the cross-check, never AUTO
+    return gemm_preferred(s->spec) ? MILE_GRAD_MFMA_WIDE_BF16X3 : MILE_GRAD_GENERIC;
   }
   return s->grad_kernel;
 }
@@ -157,7 +163,9 @@ static int choose_S(const mile_sampler *s, int E, int kernel) {
     S = std::min(S, std::max(1, NB / 4));  // keep >= 4 row blocks (one per wave) per workgroup
     return S;
   }
-  if (kernel == MILE_GRAD_GEMM_F32 || kernel == MILE_GRAD_LENET_F32) return 1;
+  if (kernel == MILE_GRAD_GEMM_F32 || kernel == MILE_GRAD_LENET_F32 || kernel == MILE_GRAD_MFMA_WIDE_BF16X3 ||
+      kernel == MILE_GRAD_MFMA_WIDE_BF16)
+    return 1;
   if (kernel == MILE_GRAD_MFMA_W128_BF16) {
     const int NBS = s->Npb / 64;              // iterations of two 32-row tiles
     int S = std::max(1, s->n_cu / std::max(E, 1));
@@ -304,6 +312,8 @@ int32_t mile_destroy(mile_sampler *s) {
   free_ws(s);
   if (s->gemm_ws) (void)hipFree(s->gemm_ws);
   if (s->gemm_ones) (void)hipFree(s->gemm_ones);
+  if (s->wide_ws) (void)hipFree(s->wide_ws);
+  if (s->wide_wt) (void)hipFree(s->wide_wt);
   if (s->dbg_buf) (void)hipFree(s->dbg_buf);
   if (s->tune_info) (void)hipFree(s->tune_info);
   if (s->blas && g_rb.destroy) (void)g_rb.destroy(s->blas);
@@ -402,7 +412,9 @@ int32_t mile_reserve(mile_sampler *s, int32_t E) {
 
 int32_t mile_set_grad_kernel(mile_sampler *s, int32_t which) {
   if (!s) return fail(MILE_ERR_INVALID, "null handle");
-  if (which < MILE_GRAD_AUTO || which > MILE_GRAD_MFMA_W64_BF16X3) return fail(MILE_ERR_INVALID, "unknown grad kernel");
+  if (which < MILE_GRAD_AUTO || which > MILE_GRAD_MFMA_WIDE_BF16) return fail(MILE_ERR_INVALID, "unknown grad kernel");
+  if ((which == MILE_GRAD_MFMA_WIDE_BF16X3 || which == MILE_GRAD_MFMA_WIDE_BF16) && s->spec.model != MILE_MODEL_FCN)
+    return fail(MILE_ERR_INVALID, "MFMA_WIDE_* are FCN kernels");
   if ((s->spec.model == MILE_MODEL_LENET) != (which == MILE_GRAD_LENET_F32) && which != MILE_GRAD_AUTO)
     return fail(MILE_ERR_INVALID, "LENET_F32 is the (only) kernel of MILE_MODEL_LENET");
   if (which == MILE_GRAD_GEMM_F32 && !rocblas_load()) return fail(MILE_ERR_HIP, "GEMM_F32 needs librocblas.so, which could not be loaded");
@@ -806,7 +818,153 @@ static int launch_grad_gemm(mile_sampler *s, const GradParams &gp, int E, hipStr
   return MILE_OK;
 }
 
-static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t st, const UpdParams *fused_update = nullptr) {
+static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t st, const UpdParams *fused_update = nullptr);
+
+// ------------------------------------------------------------------------------------
+// Layer-wise MFMA path (MILE_GRAD_MFMA_WIDE_BF16X3 / _BF16): mile_mm3.h.  Per row chunk: forward GEMM per layer with bias +
+// activation in its epilogue, head, then per layer dW (K = the chunk's rows, accumulated in place in the slab), bias
+// column sums, and the dH GEMM with the activation derivative in its epilogue.
+// ------------------------------------------------------------------------------------
+#ifndef MILE_MM_KC
+#define MILE_MM_KC 32     // K chunk of k_mm3: 32 = two workgroups per CU (mile_mm3.h); 64 = one, measured slower
+#endif
+template <int ALAY, int BSRC, int EPI, int TERMS, bool COLSUM = false>
+static hipError_t launch_mm3(const MMParams &p, int batch, hipStream_t st) {
+  constexpr int KC = MILE_MM_KC;
+  using LY = MMLayout<ALAY, BSRC, TERMS, KC>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)k_mm3<ALAY, BSRC, EPI, TERMS, KC, COLSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, LY::BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  MMParams q = p;
+  const int mtiles = (p.M + 127) / 128;
+  // row tiles per workgroup: as many as keeps >= ~8 workgroups per CU in the grid (tails), at most MILE_MM_TM
+  static const int tm_max = getenv("MILE_MM_TM") ? std::max(1, atoi(getenv("MILE_MM_TM"))) : 1;   // measured on B4: 1 = 434 ms, 4 = 438, 8 = 448 (no gain: not latency-bound)
+  int tm = 1;
+  if (!COLSUM) {
+    const long long wgs = (long long)((p.N + 127) / 128) * mtiles * batch;
+    tm = (int)std::max<long long>(1, std::min<long long>(tm_max, wgs / (256 * 2 * 8)));
+    tm = std::min(tm, mtiles);
+  }
+  q.tm_per = tm;
+  const dim3 grid((p.N + 127) / 128, (mtiles + tm - 1) / tm, batch);
+  k_mm3<ALAY, BSRC, EPI, TERMS, KC, COLSUM><<<grid, 256, LY::BYTES, st>>>(q);
+  return hipGetLastError();
+}
+
+template <int TERMS>
+static int launch_grad_wide(mile_sampler *s, const GradParams &gp, int E, hipStream_t st) {
+  const DevSpec &ds = s->ds;
+  const int L = ds.n_layers, d = ds.d, N = s->N, Fp = s->Fp;
+  auto up8 = [](int v) { return (v + 7) / 8 * 8; };
+  int wp[MILE_MAX_LAYERS], fin[MILE_MAX_LAYERS], finp[MILE_MAX_LAYERS];
+  size_t per_row = 0, wt_elems = 0, wt_off[MILE_MAX_LAYERS];
+  int maxwp = 0;
+  for (int l = 0; l < L; ++l) {
+    wp[l] = up8(ds.widths[l]);
+    fin[l] = l == 0 ? ds.in_features : ds.widths[l - 1];
+    finp[l] = l == 0 ? Fp : wp[l - 1];
+    per_row += wp[l];
+    maxwp = std::max(maxwp, wp[l]);
+    wt_off[l] = wt_elems;
+    wt_elems += (size_t)TERMS * fin[l] * wp[l];
+  }
+  per_row += 2 * (size_t)maxwp;
+  if (E != s->wide_E || !s->wide_ws) {   // activation workspace: MILE_WIDE_WS_GB (default 16 GiB of the 288), whole data set if it fits
+    double gb = 16.0;
+    if (const char *ev = getenv("MILE_WIDE_WS_GB")) gb = std::max(0.001, atof(ev));
+    const size_t budget = (size_t)(gb * (double)(1ull << 30) / 4.0);
+    size_t R = budget / ((size_t)E * per_row);
+    R = std::min<size_t>(std::max<size_t>(R, 128), (size_t)N);
+    if (R < (size_t)N) R = std::max<size_t>(128, R / 128 * 128);
+    if (const char *rv = getenv("MILE_GEMM_ROWS")) R = std::max<size_t>(1, std::min<size_t>((size_t)atoll(rv), (size_t)N));   // test hook
+    const size_t need = (size_t)E * R * per_row;
+    if (need > s->wide_ws_floats) {
+      if (s->wide_ws) (void)hipFree(s->wide_ws);
+      s->wide_ws = nullptr; s->wide_ws_floats = 0;
+      HIP_TRY(hipMalloc(&s->wide_ws, need * 4));
+      s->wide_ws_floats = need;
+    }
+    HIP_TRY(hipMemsetAsync(s->wide_ws, 0, s->wide_ws_floats * 4, st));   // padding columns are read as operands: zero, once per layout
+    s->wide_R = (int)R; s->wide_E = E;
+  }
+  const size_t wt_bytes = (size_t)E * wt_elems * 2;
+  if (wt_bytes > s->wide_wt_bytes) {
+    if (s->wide_wt) (void)hipFree(s->wide_wt);
+    s->wide_wt = nullptr; s->wide_wt_bytes = 0;
+    HIP_TRY(hipMalloc(&s->wide_wt, wt_bytes));
+    s->wide_wt_bytes = wt_bytes;
+  }
+  const int R = s->wide_R;
+  float *H[MILE_MAX_LAYERS], *tmp[2];
+  {
+    float *q = s->wide_ws;
+    for (int l = 0; l < L; ++l) { H[l] = q; q += (size_t)E * R * wp[l]; }
+    tmp[0] = q; q += (size_t)E * R * maxwp;
+    tmp[1] = q;
+  }
+  bf16 *Wt = (bf16 *)s->wide_wt;
+  // ---- this gradient's weights as zero-padded bf16 term planes [E][layer][term][in][outp]
+  for (int l = 0; l < L; ++l) {
+    const long long plane = (long long)fin[l] * wp[l];
+    k_wide_prep_weights<TERMS><<<dim3((unsigned)std::min<long long>((plane + 255) / 256, 1024), E), 256, 0, st>>>(
+        gp.theta, d, ds.w_off[l], fin[l], ds.widths[l], wp[l], Wt + wt_off[l], (long long)wt_elems);
+  }
+  float *slab = gp.slabs;        // S = 1: [E][dp]
+  const long long dp = gp.dp;
+  for (int r0 = 0, chunk = 0; r0 < N; r0 += R, ++chunk) {
+    const int Rc = std::min(R, N - r0);
+    // ---- forward
+    for (int l = 0; l < L; ++l) {
+      MMParams p{};
+      if (l == 0) { p.A = gp.Xp + (size_t)r0 * Fp; p.sA = 0; p.lda = Fp; }   // X zero-padded to Fp columns
+      else { p.A = H[l - 1]; p.sA = (long long)R * wp[l - 1]; p.lda = wp[l - 1]; }
+      p.K = fin[l];
+      p.B = Wt + wt_off[l]; p.sB = (long long)wt_elems; p.ldb = wp[l]; p.tB = (long long)fin[l] * wp[l];
+      p.C = H[l]; p.sC = (long long)R * wp[l]; p.ldc = wp[l];
+      p.M = Rc; p.N = ds.widths[l];
+      p.bias = gp.theta + ds.b_off[l]; p.sBias = d;
+      p.act = ds.activation; p.apply_act = l + 1 < L;
+      HIP_TRY((launch_mm3<MM_A_MK, MM_B_T3_KN, MM_EPI_BIAS_ACT, TERMS>(p, E, st)));
+    }
+    // ---- head: log-likelihood and d(out), in place
+    k_wide_head<<<E, 256, 0, st>>>(H[L - 1], (long long)R * wp[L - 1], wp[L - 1], gp.y, r0, Rc, ds.widths[L - 1], ds.task, gp.llpart, chunk == 0);
+    // ---- backward
+    float *dz = H[L - 1];
+    int pp = 0;
+    for (int l = L - 1; l >= 0; --l) {
+      {  // dW_l[in][out] (+)= in^T dz, straight into the slab at the kernel's offset
+        MMParams p{};
+        if (l == 0) { p.A = gp.Xp + (size_t)r0 * Fp; p.sA = 0; p.lda = Fp; }
+        else { p.A = H[l - 1]; p.sA = (long long)R * wp[l - 1]; p.lda = wp[l - 1]; }
+        p.B = dz; p.sB = (long long)R * wp[l]; p.ldb = wp[l];
+        p.C = slab + ds.w_off[l]; p.sC = dp; p.ldc = ds.widths[l];
+        p.M = fin[l]; p.N = ds.widths[l]; p.K = Rc;
+        p.accumulate = chunk != 0;
+        p.colsum = slab + ds.b_off[l]; p.sColsum = dp;      // bias gradient dz^T 1 from the B tiles of M tile 0
+        HIP_TRY((launch_mm3<MM_A_KM, MM_B_F32_KN, MM_EPI_STORE, TERMS, true>(p, E, st)));
+      }
+      if (l > 0) {   // dZ_{l-1} = (dz W_l^T) * act'(H_{l-1})
+        MMParams p{};
+        p.A = dz; p.sA = (long long)R * wp[l]; p.lda = wp[l]; p.K = ds.widths[l];
+        p.B = Wt + wt_off[l]; p.sB = (long long)wt_elems; p.ldb = wp[l]; p.tB = (long long)fin[l] * wp[l];
+        p.C = tmp[pp]; p.sC = (long long)R * wp[l - 1]; p.ldc = wp[l - 1];
+        p.M = Rc; p.N = fin[l];
+        p.Hprev = H[l - 1]; p.sH = (long long)R * wp[l - 1]; p.ldh = wp[l - 1];
+        p.act = ds.activation;
+        HIP_TRY((launch_mm3<MM_A_MK, MM_B_T3_NK, MM_EPI_ACT_GRAD, TERMS>(p, E, st)));
+        dz = tmp[pp];
+        pp ^= 1;
+      }
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return MILE_OK;
+}
+
+static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t st, const UpdParams *fused_update) {
   if (!s->X) return fail(MILE_ERR_STATE, "no data: call mile_set_data first");
   const int kernel = resolved_kernel(s);
   const int S = choose_S(s, E, kernel);
@@ -862,6 +1020,9 @@ static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t s
     if (rc) return rc;
   } else if (kernel == MILE_GRAD_GEMM_F32) {
     const int rc = launch_grad_gemm(s, gp, E, st);
+    if (rc) return rc;
+  } else if (kernel == MILE_GRAD_MFMA_WIDE_BF16X3 || kernel == MILE_GRAD_MFMA_WIDE_BF16) {
+    const int rc = kernel == MILE_GRAD_MFMA_WIDE_BF16X3 ? launch_grad_wide<3>(s, gp, E, st) : launch_grad_wide<1>(s, gp, E, st);
     if (rc) return rc;
   } else if (kernel == MILE_GRAD_MFMA_W128_BF16) {
     if (!s->Xb) return fail(MILE_ERR_STATE, "bf16 data copies missing: call mile_set_data");
@@ -970,6 +1131,77 @@ static int launch_fwd_gemm(mile_sampler *s, const float *theta, int S, const flo
   return MILE_OK;
 }
 
+// Evaluation forward for wide nets on the MFMA GEMMs (fp32-faithful, whatever the sampling kernel was): samples as the batch.
+static int launch_fwd_wide(mile_sampler *s, const float *theta, int S, const float *Xp, int Fp, const void *y, int N, float *out,
+                           hipStream_t st) {
+  const DevSpec &ds = s->ds;
+  const int L = ds.n_layers, d = ds.d;
+  auto up8 = [](int v) { return (v + 7) / 8 * 8; };
+  int wp[MILE_MAX_LAYERS], fin[MILE_MAX_LAYERS];
+  size_t wt_elems = 0, wt_off[MILE_MAX_LAYERS];
+  int maxwp = 0;
+  for (int l = 0; l < L; ++l) {
+    wp[l] = up8(ds.widths[l]);
+    fin[l] = l == 0 ? ds.in_features : ds.widths[l - 1];
+    maxwp = std::max(maxwp, wp[l]);
+    wt_off[l] = wt_elems;
+    wt_elems += (size_t)3 * fin[l] * wp[l];
+  }
+  const int Sc = std::min(S, 512);
+  size_t Rr = ((size_t)1 << 28) / (2 * (size_t)Sc * maxwp);           // two ping-pong buffers, <= 1 GiB of floats
+  Rr = std::max<size_t>(1, std::min<size_t>(Rr, (size_t)N));
+  if (const char *rv = getenv("MILE_GEMM_ROWS")) Rr = std::max<size_t>(1, std::min<size_t>((size_t)atoll(rv), (size_t)N));
+  const int R = (int)Rr;
+  const size_t need = 2 * (size_t)Sc * R * maxwp;
+  if (need > s->wide_ws_floats) {
+    if (s->wide_ws) (void)hipFree(s->wide_ws);
+    s->wide_ws = nullptr; s->wide_ws_floats = 0;
+    HIP_TRY(hipMalloc(&s->wide_ws, need * 4));
+    s->wide_ws_floats = need;
+  }
+  s->wide_E = 0;   // the gradient path re-derives (and re-zeroes) its layout on its next call
+  const size_t wt_bytes = (size_t)Sc * wt_elems * 2;
+  if (wt_bytes > s->wide_wt_bytes) {
+    if (s->wide_wt) (void)hipFree(s->wide_wt);
+    s->wide_wt = nullptr; s->wide_wt_bytes = 0;
+    HIP_TRY(hipMalloc(&s->wide_wt, wt_bytes));
+    s->wide_wt_bytes = wt_bytes;
+  }
+  float *buf[2] = {s->wide_ws, s->wide_ws + (size_t)Sc * R * maxwp};
+  bf16 *Wt = (bf16 *)s->wide_wt;
+  for (int s0 = 0; s0 < S; s0 += Sc) {
+    const int Sn = std::min(Sc, S - s0);
+    const float *th = theta + (size_t)s0 * d;
+    for (int l = 0; l < L; ++l) {
+      const long long plane = (long long)fin[l] * wp[l];
+      k_wide_prep_weights<3><<<dim3((unsigned)std::min<long long>((plane + 255) / 256, 1024), Sn), 256, 0, st>>>(
+          th, d, ds.w_off[l], fin[l], ds.widths[l], wp[l], Wt + wt_off[l], (long long)wt_elems);
+    }
+    for (int r0 = 0; r0 < N; r0 += R) {
+      const int Rc = std::min(R, N - r0);
+      // layers of different widths share the two buffers: padding columns an operand read may touch must be zero
+      HIP_TRY(hipMemsetAsync(s->wide_ws, 0, need * 4, st));
+      int pp = 0;
+      for (int l = 0; l < L; ++l) {
+        MMParams p{};
+        if (l == 0) { p.A = Xp + (size_t)r0 * Fp; p.sA = 0; p.lda = Fp; }
+        else { p.A = buf[pp ^ 1]; p.sA = (long long)R * wp[l - 1]; p.lda = wp[l - 1]; }
+        p.K = fin[l];
+        p.B = Wt + wt_off[l]; p.sB = (long long)wt_elems; p.ldb = wp[l]; p.tB = (long long)fin[l] * wp[l];
+        p.C = buf[pp]; p.sC = (long long)R * wp[l]; p.ldc = wp[l];
+        p.M = Rc; p.N = ds.widths[l];
+        p.bias = th + ds.b_off[l]; p.sBias = d;
+        p.act = ds.activation; p.apply_act = l + 1 < L;
+        HIP_TRY((launch_mm3<MM_A_MK, MM_B_T3_KN, MM_EPI_BIAS_ACT, 3>(p, Sn, st)));
+        pp ^= 1;
+      }
+      k_wide_rowll<<<dim3((Rc + 255) / 256, Sn), 256, 0, st>>>(buf[pp ^ 1], (long long)R * wp[L - 1], wp[L - 1], y, r0, Rc, ds.widths[L - 1], ds.task, out, N, s0);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return MILE_OK;
+}
+
 extern "C" int32_t mile_pointwise_loglik(mile_sampler *s, const float *theta, int32_t S, const float *X, const void *y,
                                          int64_t N, float *out, void *stream) {
   if (!s || !theta || !X || !y || !out || S < 1) return fail(MILE_ERR_INVALID, "mile_pointwise_loglik: bad argument");
@@ -1003,9 +1235,10 @@ extern "C" int32_t mile_pointwise_loglik(mile_sampler *s, const float *theta, in
     }
     return MILE_OK;
   }
-  if (kernel == MILE_GRAD_GEMM_F32 || (kernel == MILE_GRAD_MFMA_W128_BF16 && rocblas_load())) {
-    // wide nets: evaluation stays fp32 whatever the sampling kernel was
-    return launch_fwd_gemm(s, theta, S, s->ev_X, s->ev_y, (int)N, out, st);
+  if (kernel == MILE_GRAD_GEMM_F32) return launch_fwd_gemm(s, theta, S, s->ev_X, s->ev_y, (int)N, out, st);
+  if (kernel == MILE_GRAD_MFMA_WIDE_BF16X3 || kernel == MILE_GRAD_MFMA_WIDE_BF16 || kernel == MILE_GRAD_MFMA_W128_BF16) {
+    // wide nets: evaluation stays fp32-faithful whatever the sampling kernel was
+    return launch_fwd_wide(s, theta, S, s->ev_Xp, Fp, s->ev_y, (int)N, out, st);
   }
   if (is_w64(kernel)) {
     const int NB = Npad / 32;

@@ -1,0 +1,470 @@
+// k_mm3: batched C = A.B on the gfx950 bf16 matrix pipe with fp32-faithful products -- the Dense products of WIDE nets
+// (BASELINE config B4: [54 -> 256 x 4 -> 7], softmax head; anything whose hidden layers do not fit the fused kernels).
+//
+// Why not one fused forward+backward kernel as for widths 64 / 128: at width 256 a particle's three hidden matrices are
+// 786 KB as fp32 (1.2 MB as bf16 terms) and its weight-gradient accumulators 768 KB -- neither fits a CU (160 KB LDS,
+// 512 KB of registers), so the row-resident design of k_grad_w64 / k_grad_w128b has nowhere to keep them.  At this width
+// the Dense products are real GEMMs (K = 256, or K = all data rows for dW): the layer-wise schedule of mile_hip.hip
+// (launch_grad_wide) runs them here, with everything elementwise fused into the GEMM that produces or consumes it:
+//   forward   H_l  = act(H_{l-1} W_l + b_l)                 A = activations [rows][in],  B = W_l terms [in][out]
+//   dH        dZ_{l-1} = (dZ_l W_l^T) * act'(H_{l-1})       A = dZ_l [rows][out],        B = W_l terms read as [in][out] rows
+//   dW        dW_l (+)= H_{l-1}^T dZ_l                      A = H_{l-1} read transposed,  B = dZ_l [rows][out]; K = data rows
+// (src/flax_building_blocks/basic.py:42-61; the likelihood head and its skinny products are k_wide_head.)
+//
+// Arithmetic: every fp32 operand is the exact sum of three bf16 terms (top / middle / bottom 8 significand bits); a product
+// a.b is accumulated in fp32 from the six bf16 MFMA products a3b1 a1b3 a2b2 a2b1 a1b2 a1b1 (the three dropped ones are
+// below 2^-23 of a1b1) -- the scheme of k_grad_w64<.., SPLIT>, 3/8 of the fp32-MFMA time at fp32 accuracy.
+// Here the split is paid once per operand element per workgroup tile and reused by 128 output columns / rows, and the
+// weights arrive pre-split (k_wide_prep_weights), so it is a few % of the MFMA time instead of half of it.
+// TERMS = 1 gives the bf16-operand form (one product, operands rounded to nearest-even) for callers that ask for it.
+//
+// Tiling: workgroup = 4 waves = one per SIMD, C tile 128 x 128, K chunk 64; wave (wm, wn) owns a 64 x 64 quadrant = 2 x 2
+// MFMA tiles (64 accumulator registers).  Operand tiles live in LDS as swizzled bf16 term images (mile_bf16_frag.h: one
+// layout serves row reads ds_read_b128 and transposed reads ds_read_b64_tr_b16, conflict-free), single-buffered: the next
+// chunk's global loads are issued before the 96 MFMAs of the current chunk and are split / stored behind them.
+// grid = (N tiles, M tiles, batch): the batch (particle) index is slowest, so concurrently running workgroups share one
+// particle's weights in L2.
+#pragma once
+#include "mile_bf16_frag.h"
+#include "mile_device.h"
+#include "mile_grad_generic.h"
+
+enum { MM_A_MK = 0, MM_A_KM = 1 };                       // A given as [M][K] (K contiguous) or as [K][M] (read transposed)
+enum { MM_B_F32_KN = 0, MM_B_T3_KN = 1, MM_B_T3_NK = 2 };   // B: fp32 [K][N]; bf16 term planes [K][N]; term planes [N][K]
+enum { MM_EPI_STORE = 0, MM_EPI_BIAS_ACT = 1, MM_EPI_ACT_GRAD = 2 };
+
+struct MMParams {
+  const float *A; long long sA; int lda;     // batch stride and leading dimension in floats (lda % 4 == 0, 16-byte aligned)
+  const void *B; long long sB; int ldb;      // fp32: as A.  Term planes: bf16 elements, ldb % 8 == 0, tB = plane stride
+  long long tB;
+  float *C; long long sC; int ldc;
+  int M, N, K;
+  const float *bias; long long sBias;        // MM_EPI_BIAS_ACT: bias[n] (any alignment)
+  const float *Hprev; long long sH; int ldh; // MM_EPI_ACT_GRAD: activation OUTPUT whose derivative multiplies C
+  int act, apply_act, accumulate;            // accumulate: C += (row chunks of dW)
+  float *colsum; long long sColsum;          // COLSUM: column sums of B over K -> colsum[bz * sColsum + n] (any alignment)
+  int tm_per;                                // consecutive 128-row C tiles per workgroup (>= 1; 1 when COLSUM)
+};
+
+typedef uint32_t mm_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t mm_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t mm_hi16_pair(float x1, float x0) {   // {bf16 bits of x1 : bf16 bits of x0}, truncating
+  return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+}
+__device__ __forceinline__ float mm_trunc(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+
+// four fp32 values -> TERMS packed bf16 quadruples (8 bytes each)
+template <int TERMS>
+__device__ __forceinline__ void mm_split4(const f32x4 x, mm_u32x2 (&pk)[TERMS]) {
+  if constexpr (TERMS == 1) {
+    const bf16x4 b = __builtin_convertvector(x, bf16x4);   // round to nearest even (v_cvt_pk_bf16_f32)
+    pk[0] = __builtin_bit_cast(mm_u32x2, b);
+  } else {
+    static_assert(TERMS == 3, "one or three terms");
+    pk[0] = mm_u32x2{mm_hi16_pair(x[1], x[0]), mm_hi16_pair(x[3], x[2])};
+    const f32x4 r = {x[0] - mm_trunc(x[0]), x[1] - mm_trunc(x[1]), x[2] - mm_trunc(x[2]), x[3] - mm_trunc(x[3])};
+    pk[1] = mm_u32x2{mm_hi16_pair(r[1], r[0]), mm_hi16_pair(r[3], r[2])};
+    const f32x4 q = {r[0] - mm_trunc(r[0]), r[1] - mm_trunc(r[1]), r[2] - mm_trunc(r[2]), r[3] - mm_trunc(r[3])};
+    pk[2] = mm_u32x2{mm_hi16_pair(q[1], q[0]), mm_hi16_pair(q[3], q[2])};
+  }
+}
+
+// LDS image geometry (KC = K chunk, 32 or 64).  "Row-major K" tiles ([128 rows][KC k]: A_MK, B_NK) pack their terms side by
+// side in 128-column images -- KC = 64: term 0 in columns 0..63 and term 1 in columns 64..127 of image 0, term 2 in columns
+// 0..63 of image 1; KC = 32: term t in columns 32 t .. 32 t + 31 of one image.  "K-major" tiles ([KC k][128 cols]: A_KM, B_KN)
+// take one KC-row image per term.  KC = 32 keeps a workgroup at <= 64 KB so that TWO fit a CU: one's global-load / split /
+// store phases and epilogue then run under the other's MFMAs (one wave per SIMD has nothing else to hide them behind).
+template <int TERMS, int KC> __host__ __device__ constexpr int mm_rowk_bytes() { return (KC == 64 && TERMS == 3 ? 2 : 1) * 128 * 256; }
+template <int TERMS, int KC> __host__ __device__ constexpr int mm_kmaj_bytes() { return TERMS * KC * 256; }
+template <int KC> __device__ __forceinline__ int mm_rowk_img(int t) { return (KC == 64 && t == 2) ? 128 * 256 : 0; }
+template <int KC> __device__ __forceinline__ int mm_rowk_ch(int t) { return KC == 64 ? (t == 1 ? 8 : 0) : 4 * t; }
+
+template <int ALAY, int BSRC, int TERMS, int KC>
+struct MMLayout {
+  static constexpr int A_BYTES = ALAY == MM_A_MK ? mm_rowk_bytes<TERMS, KC>() : mm_kmaj_bytes<TERMS, KC>();
+  static constexpr int B_BYTES = BSRC == MM_B_T3_NK ? mm_rowk_bytes<TERMS, KC>() : mm_kmaj_bytes<TERMS, KC>();
+  static constexpr int BYTES = A_BYTES + B_BYTES;
+};
+
+// COLSUM (dW form only: B = dZ as fp32 [K rows][N]): the workgroups of M tile 0 also sum the columns of B over all K rows --
+// the bias gradient dZ^T 1 -- from the B tiles they stage anyway, and write it to p.colsum (fixed order: deterministic).
+#ifndef MILE_MM_PF
+#define MILE_MM_PF 1      // chunks of global loads in flight ahead of the MFMAs (register stages of the fp32 operands)
+#endif
+#ifndef MILE_MM_OCC
+#define MILE_MM_OCC 2     // workgroups per CU the register allocation is sized for
+#endif
+template <int ALAY, int BSRC, int EPI, int TERMS, int KC, bool COLSUM = false>
+__global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
+  using LY = MMLayout<ALAY, BSRC, TERMS, KC>;
+  static_assert(KC == 32 || KC == 64, "K chunk");
+  static_assert(!COLSUM || BSRC == MM_B_F32_KN, "column sums come from an fp32 B operand");
+  extern __shared__ __attribute__((aligned(16))) char mm_smem[];
+  char *Aimg = mm_smem, *Bimg = mm_smem + LY::A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int bz = blockIdx.z, n0 = blockIdx.x * 128;
+  // a workgroup walks p.tm_per consecutive 128-row tiles of C (same columns, same batch entry) as ONE software pipeline:
+  // the first chunk of the next tile is in flight under the last MFMAs and the epilogue of the current one (with K = 256
+  // a tile is only 8 chunks: loading its first chunk cold and draining its stores would otherwise dominate)
+  const int mtiles = (p.M + 127) / 128, mt_first = blockIdx.y * p.tm_per;
+  const int ntile_wg = min(p.tm_per, mtiles - mt_first);
+  const int M = p.M, N = p.N, K = p.K;
+  const float *A = p.A + (size_t)bz * p.sA;
+  float *C = p.C + (size_t)bz * p.sC;
+
+  // ---- global -> register staging of one K chunk -------------------------------------------------------------------
+  // fp32 tiles, one float4 per thread and pass.  [128 rows][KC k]: KC / 4 threads per row; [KC k][128 cols]: 32 per row.
+  constexpr int A_TPR = KC / 4, A_NP = ALAY == MM_A_MK ? A_TPR / 2 : KC / 8;
+  constexpr int PF = MILE_MM_PF;
+  f32x4 ra[PF][A_NP];
+  auto load_a = [&](const int st, const int m0, int k0) {
+    if constexpr (ALAY == MM_A_MK) {
+      const int c4 = tid % A_TPR, r0 = tid / A_TPR;
+#pragma unroll
+      for (int i = 0; i < A_NP; ++i) {
+        const int m = m0 + r0 + (256 / A_TPR) * i, k = k0 + 4 * c4;
+        ra[st][i] = (m < M && k < K) ? *(const f32x4 *)(A + (size_t)m * p.lda + k) : f32x4{0, 0, 0, 0};
+      }
+    } else {
+      const int c4 = tid & 31, r0 = tid >> 5;
+#pragma unroll
+      for (int i = 0; i < A_NP; ++i) {
+        const int k = k0 + r0 + 8 * i, m = m0 + 4 * c4;
+        ra[st][i] = (k < K && m < M) ? *(const f32x4 *)(A + (size_t)k * p.lda + m) : f32x4{0, 0, 0, 0};
+      }
+    }
+  };
+  auto store_a = [&](const int st) {
+    if constexpr (ALAY == MM_A_MK) {
+      const int c4 = tid % A_TPR, r0 = tid / A_TPR;
+#pragma unroll
+      for (int i = 0; i < A_NP; ++i) {
+        mm_u32x2 pk[TERMS];
+        mm_split4<TERMS>(ra[st][i], pk);
+#pragma unroll
+        for (int t = 0; t < TERMS; ++t)
+          *reinterpret_cast<mm_u32x2 *>(Aimg + mm_rowk_img<KC>(t) + img_off(r0 + (256 / A_TPR) * i, mm_rowk_ch<KC>(t) + (c4 >> 1)) + 8 * (c4 & 1)) = pk[t];
+      }
+    } else {
+      const int c4 = tid & 31, r0 = tid >> 5;
+#pragma unroll
+      for (int i = 0; i < A_NP; ++i) {
+        mm_u32x2 pk[TERMS];
+        mm_split4<TERMS>(ra[st][i], pk);
+#pragma unroll
+        for (int t = 0; t < TERMS; ++t)
+          *reinterpret_cast<mm_u32x2 *>(Aimg + t * KC * 256 + img_off(r0 + 8 * i, c4 >> 1) + 8 * (c4 & 1)) = pk[t];
+      }
+    }
+  };
+  // B: fp32 [K][N] (split here) or pre-split bf16 term planes (16-byte chunks straight into the images)
+  constexpr int BF_NP = KC / 8;                                   // fp32 [KC k][128 n]: passes of 8 k rows
+  constexpr int BT_NP = KC / 16;                                  // term planes: KN 16 k rows per pass; NK 2048 / KC n rows per pass
+  constexpr int NK_CPR = KC / 8;                                  // NK: 16-byte chunks per n row
+  f32x4 rb[BSRC == MM_B_F32_KN ? PF : 1][BSRC == MM_B_F32_KN ? BF_NP : 1];
+  mm_u32x4 rbt[BSRC == MM_B_F32_KN ? 1 : TERMS][BT_NP];
+  float csum[4] = {0.0f, 0.0f, 0.0f, 0.0f};                        // COLSUM: this thread's four columns, its k rows
+  auto load_b = [&](const int st, int k0) {
+    if constexpr (BSRC == MM_B_F32_KN) {
+      const float *B = (const float *)p.B + (size_t)bz * p.sB;
+      const int c4 = tid & 31, r0 = tid >> 5;
+#pragma unroll
+      for (int i = 0; i < BF_NP; ++i) {
+        const int k = k0 + r0 + 8 * i, n = n0 + 4 * c4;
+        rb[st][i] = (k < K && n < N) ? *(const f32x4 *)(B + (size_t)k * p.ldb + n) : f32x4{0, 0, 0, 0};
+      }
+    } else if constexpr (BSRC == MM_B_T3_KN) {
+      const bf16 *B = (const bf16 *)p.B + (size_t)bz * p.sB;
+      const int c = tid & 15, r0 = tid >> 4;          // [KC k][128 n]: 16 chunks of 8 columns per row
+#pragma unroll
+      for (int t = 0; t < TERMS; ++t)
+#pragma unroll
+        for (int i = 0; i < BT_NP; ++i) {
+          const int k = k0 + r0 + 16 * i, n = n0 + 8 * c;
+          rbt[t][i] = (k < K && n < N) ? *(const mm_u32x4 *)(B + (size_t)t * p.tB + (size_t)k * p.ldb + n) : mm_u32x4{0, 0, 0, 0};
+        }
+    } else {
+      const bf16 *B = (const bf16 *)p.B + (size_t)bz * p.sB;
+      const int c = tid % NK_CPR, r0 = tid / NK_CPR;  // [128 n][KC k]: KC / 8 chunks of 8 k per row
+#pragma unroll
+      for (int t = 0; t < TERMS; ++t)
+#pragma unroll
+        for (int i = 0; i < BT_NP; ++i) {
+          const int n = n0 + r0 + (256 / NK_CPR) * i, k = k0 + 8 * c;
+          rbt[t][i] = (n < N && k < K) ? *(const mm_u32x4 *)(B + (size_t)t * p.tB + (size_t)n * p.ldb + k) : mm_u32x4{0, 0, 0, 0};
+        }
+    }
+  };
+  auto store_b = [&](const int st) {
+    if constexpr (BSRC == MM_B_F32_KN) {
+      const int c4 = tid & 31, r0 = tid >> 5;
+#pragma unroll
+      for (int i = 0; i < BF_NP; ++i) {
+        if constexpr (COLSUM) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) csum[q] += rb[st][i][q];
+        }
+        mm_u32x2 pk[TERMS];
+        mm_split4<TERMS>(rb[st][i], pk);
+#pragma unroll
+        for (int t = 0; t < TERMS; ++t)
+          *reinterpret_cast<mm_u32x2 *>(Bimg + t * KC * 256 + img_off(r0 + 8 * i, c4 >> 1) + 8 * (c4 & 1)) = pk[t];
+      }
+    } else if constexpr (BSRC == MM_B_T3_KN) {
+      const int c = tid & 15, r0 = tid >> 4;
+#pragma unroll
+      for (int t = 0; t < TERMS; ++t)
+#pragma unroll
+        for (int i = 0; i < BT_NP; ++i) *reinterpret_cast<mm_u32x4 *>(Bimg + t * KC * 256 + img_off(r0 + 16 * i, c)) = rbt[t][i];
+    } else {
+      const int c = tid % NK_CPR, r0 = tid / NK_CPR;
+#pragma unroll
+      for (int t = 0; t < TERMS; ++t)
+#pragma unroll
+        for (int i = 0; i < BT_NP; ++i)
+          *reinterpret_cast<mm_u32x4 *>(Bimg + mm_rowk_img<KC>(t) + img_off(r0 + (256 / NK_CPR) * i, mm_rowk_ch<KC>(t) + c)) = rbt[t][i];
+    }
+  };
+
+  f32x16 acc[2][2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.0f;
+  };
+  zero_acc();
+  // 32 x 32 tiles of this wave that lie inside the matrix (skinny products skip the MFMAs of the rest; wave-uniform)
+  bool mt_on[2], nt_on[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) nt_on[q] = n0 + 64 * wn + 32 * q < N;
+
+  // ---- epilogue of one C tile: D[m = acc_m(reg, h)][n = r] per 32 x 32 MFMA tile ---------------------------------------
+  auto epilogue = [&](const int m0) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        if (!(mt_on[a] && nt_on[b])) continue;
+        const int n = n0 + 64 * wn + 32 * b + r;
+        if (n >= N) continue;
+        float bias = 0.0f;
+        if constexpr (EPI == MM_EPI_BIAS_ACT) bias = p.bias[(size_t)bz * p.sBias + n];
+        const int mb = m0 + 64 * wm + 32 * a + 4 * h;            // row of register q: mb + (q & 3) + 8 (q >> 2)
+        float *crow = C + (size_t)mb * p.ldc + n;
+        const float *hrow = EPI == MM_EPI_ACT_GRAD ? p.Hprev + (size_t)bz * p.sH + (size_t)mb * p.ldh + n : nullptr;
+        const bool full = mb + 28 <= M;                           // all 16 rows of this lane inside the matrix
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int dm = (q & 3) + 8 * (q >> 2);
+          if (!full && mb + dm >= M) continue;
+          float v = acc[a][b][q];
+          if constexpr (EPI == MM_EPI_BIAS_ACT) {
+            v += bias;
+            if (p.apply_act) v = act_fwd(p.act, v);
+          }
+          if constexpr (EPI == MM_EPI_ACT_GRAD) v *= act_bwd(p.act, hrow[(size_t)dm * p.ldh]);
+          float *c = crow + (size_t)dm * p.ldc;
+          if (p.accumulate) v += *c;
+          *c = v;
+        }
+      }
+  };
+
+  const int nk = (K + KC - 1) / KC;
+  const int total = ntile_wg * nk;                 // chunks of this workgroup, tile-major
+  // software pipeline: the fp32 operands of chunks g+1 .. g+PF are in flight (register stage = chunk % PF) while chunk g is
+  // multiplied; pre-split weight planes (L2-resident) stay one chunk ahead.  Chunk g = (tile g / nk, K chunk g % nk).
+  constexpr bool B_DEEP = BSRC == MM_B_F32_KN;
+  auto chunk_m0 = [&](int g) { return (mt_first + g / nk) * 128; };
+  auto chunk_k0 = [&](int g) { return KC * (g % nk); };
+#pragma unroll
+  for (int j = 0; j < PF; ++j)
+    if (j < total) {
+      load_a(j, chunk_m0(j), chunk_k0(j));
+      if (B_DEEP || j == 0) load_b(B_DEEP ? j : 0, chunk_k0(j));
+    }
+  for (int g0 = 0; g0 < total; g0 += PF)
+#pragma unroll
+  for (int j = 0; j < PF; ++j) {
+    const int g = g0 + j;
+    if (g >= total) break;
+    const int kc = g % nk, m0 = chunk_m0(g);
+    if (kc == 0) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) mt_on[q] = m0 + 64 * wm + 32 * q < M;
+    }
+    __syncthreads();          // every wave has read the previous chunk's images
+    store_a(j);
+    store_b(B_DEEP ? j : 0);
+    __syncthreads();
+    if (g + PF < total) load_a(j, chunk_m0(g + PF), chunk_k0(g + PF));       // refill this stage
+    if (B_DEEP) { if (g + PF < total) load_b(j, chunk_k0(g + PF)); }
+    else if (g + 1 < total) load_b(0, chunk_k0(g + 1));
+    const int ksteps = min(KC / 16, (K - KC * kc + 15) / 16);
+    auto kstep = [&](const int ks) {
+      bf16x8 af[2][TERMS], bfr[2][TERMS];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int t = 0; t < TERMS; ++t) {
+          if constexpr (ALAY == MM_A_MK) af[q][t] = row_frag(Aimg + mm_rowk_img<KC>(t), 64 * wm + 32 * q + r, mm_rowk_ch<KC>(t) + 2 * ks + h);
+          else af[q][t] = tr_frag(Aimg + t * KC * 256, 16 * ks, 64 * wm + 32 * q, lane);
+          if constexpr (BSRC == MM_B_T3_NK) bfr[q][t] = row_frag(Bimg + mm_rowk_img<KC>(t), 64 * wn + 32 * q + r, mm_rowk_ch<KC>(t) + 2 * ks + h);
+          else bfr[q][t] = tr_frag(Bimg + t * KC * 256, 16 * ks, 64 * wn + 32 * q, lane);
+        }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          if (!(mt_on[a] && nt_on[b])) continue;
+          if constexpr (TERMS == 3) {   // small terms first
+            acc[a][b] = mfma_bf16(af[a][2], bfr[b][0], acc[a][b]);
+            acc[a][b] = mfma_bf16(af[a][0], bfr[b][2], acc[a][b]);
+            acc[a][b] = mfma_bf16(af[a][1], bfr[b][1], acc[a][b]);
+            acc[a][b] = mfma_bf16(af[a][1], bfr[b][0], acc[a][b]);
+            acc[a][b] = mfma_bf16(af[a][0], bfr[b][1], acc[a][b]);
+          }
+          acc[a][b] = mfma_bf16(af[a][0], bfr[b][0], acc[a][b]);
+        }
+    };
+    if (ksteps == KC / 16) {  // full chunk: constant image offsets
+#pragma unroll
+      for (int ks = 0; ks < KC / 16; ++ks) kstep(ks);
+    } else {
+      for (int ks = 0; ks < ksteps; ++ks) kstep(ks);
+    }
+    if (kc == nk - 1) {       // this C tile is complete (the next tile's first chunk is already in flight)
+      epilogue(m0);
+      zero_acc();
+    }
+  }
+  if constexpr (COLSUM) {
+    if (blockIdx.y == 0) {     // thread (c4, r0) holds columns n0 + 4 c4 .. + 3 summed over its k rows: add the 8 row groups
+      __syncthreads();
+      float *red = reinterpret_cast<float *>(mm_smem);                    // [8][128]
+      const int c4 = tid & 31, r0 = tid >> 5;
+      *reinterpret_cast<f32x4 *>(red + r0 * 128 + 4 * c4) = f32x4{csum[0], csum[1], csum[2], csum[3]};
+      __syncthreads();
+      if (tid < 128 && n0 + tid < N) {
+        float t = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += red[g * 128 + tid];
+        float *o = p.colsum + (size_t)bz * p.sColsum + n0 + tid;
+        *o = p.accumulate ? *o + t : t;
+      }
+    }
+  }
+}
+
+// ---- weights of one layer -> zero-padded bf16 term planes Wt[e][t][in][outp] ------------------------------------------
+// theta rows are d floats apart (any alignment); outp = out rounded up to 8 so that every plane row is 16-byte aligned.
+template <int TERMS>
+__global__ __launch_bounds__(256) void k_wide_prep_weights(const float *theta, long long d, int w_off, int fin, int fout, int outp,
+                                                          bf16 *Wt, long long sW) {
+  const int e = blockIdx.y;
+  const float *W = theta + (size_t)e * d + w_off;
+  bf16 *o = Wt + (size_t)e * sW;
+  const long long plane = (long long)fin * outp;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < plane; idx += (long long)gridDim.x * 256) {
+    const int i = (int)(idx / outp), c = (int)(idx % outp);
+    const float x = c < fout ? W[(size_t)i * fout + c] : 0.0f;
+    if constexpr (TERMS == 1) {
+      o[idx] = (bf16)x;
+    } else {
+      const float x1 = mm_trunc(x), r1 = x - x1, x2 = mm_trunc(r1), x3 = r1 - x2;
+      o[idx] = __builtin_bit_cast(bf16, (uint16_t)(__float_as_uint(x1) >> 16));
+      o[plane + idx] = __builtin_bit_cast(bf16, (uint16_t)(__float_as_uint(x2) >> 16));
+      o[2 * plane + idx] = __builtin_bit_cast(bf16, (uint16_t)(__float_as_uint(x3) >> 16));
+    }
+  }
+}
+
+// ---- head: per-row log-likelihood and d/d(out) in place on out [E][R][ld] (ld >= K, padding untouched = 0) -------------
+// src/training/probabilistic.py:92-109 (nansum: NaN rows contribute nothing); one workgroup per particle, fixed order.
+__global__ __launch_bounds__(256) void k_wide_head(float *out, long long sOut, int ld, const void *y, long long r0, int R, int K, int task,
+                                                   float *llacc, int first_chunk) {
+  __shared__ float red[4];
+  const int e = blockIdx.x, tid = threadIdx.x;
+  float *o = out + (size_t)e * sOut;
+  float ll = 0.0f;
+  for (int rr = tid; rr < R; rr += 256) {
+    float *z = o + (size_t)rr * ld;
+    if (task == MILE_TASK_REGRESSION) {
+      float dmu, ds;
+      ll += row_loss_regr(z[0], z[1], ((const float *)y)[r0 + rr], dmu, ds);
+      z[0] = dmu; z[1] = ds;
+    } else {
+      const int yi = ((const int32_t *)y)[r0 + rr];
+      float m = z[0];
+      for (int c = 1; c < K; ++c) m = fmaxf(m, z[c]);
+      float se = 0.0f;
+      for (int c = 0; c < K; ++c) se += expf(z[c] - m);
+      const float lse = m + logf(se);
+      const float l1 = z[yi] - lse;
+      const bool bad = isnan(l1);
+      for (int c = 0; c < K; ++c) z[c] = bad ? 0.0f : ((c == yi ? 1.0f : 0.0f) - expf(z[c] - lse));
+      ll += bad ? 0.0f : l1;
+    }
+  }
+  ll = wave_sum(ll);
+  if ((tid & 63) == 0) red[tid >> 6] = ll;
+  __syncthreads();
+  if (tid == 0) {
+    const float t = (red[0] + red[1]) + (red[2] + red[3]);
+    llacc[e] = first_chunk ? t : llacc[e] + t;
+  }
+}
+
+// ---- bias gradient: column sums of dZ [E][R][ld] -> slab[e * dp + b_off + c] (+)= ---------------------------------------
+// workgroup = (64-column block, particle); a wave walks rows with one column per lane (256-byte coalesced reads).
+__global__ __launch_bounds__(256) void k_wide_colsum(const float *dZ, long long sZ, int ld, int R, int W, float *slab, long long dp, int b_off,
+                                                     int accumulate) {
+  __shared__ float red[4][64];
+  const int e = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  const float *z = dZ + (size_t)e * sZ;
+  float s0 = 0.0f, s1 = 0.0f;
+  if (c < W) {
+    int rr = w;
+    for (; rr + 4 < R; rr += 8) { s0 += z[(size_t)rr * ld + c]; s1 += z[(size_t)(rr + 4) * ld + c]; }
+    for (; rr < R; rr += 4) s0 += z[(size_t)rr * ld + c];
+  }
+  red[w][threadIdx.x & 63] = s0 + s1;
+  __syncthreads();
+  if (w == 0 && c < W) {
+    const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    float *o = slab + (size_t)e * dp + b_off + c;
+    *o = accumulate ? *o + t : t;
+  }
+}
+
+// ---- evaluation: per-row log-likelihood of the head outputs out [S][R][ld] -> out_ll[(s0 + s) * N + r0 + r] ------------
+// (no nansum zeroing: src/inference/metrics.py:247-294 uses the distributions' log_prob directly)
+__global__ __launch_bounds__(256) void k_wide_rowll(const float *out, long long sOut, int ld, const void *y, long long r0, int R, int K, int task,
+                                                    float *out_ll, long long N, long long s0) {
+  const int s = blockIdx.y;
+  const float *o = out + (size_t)s * sOut;
+  for (int rr = blockIdx.x * 256 + threadIdx.x; rr < R; rr += gridDim.x * 256) {
+    const float *z = o + (size_t)rr * ld;
+    float v;
+    if (task == MILE_TASK_REGRESSION) {
+      const float es = expf(z[1]);
+      const float sig = isnan(es) ? es : fminf(fmaxf(es, 1e-6f), 1e6f);
+      const float q = (((const float *)y)[r0 + rr] - z[0]) / sig;
+      v = -0.5f * q * q - logf(sig) - 0.91893853320467274f;
+    } else {
+      const int yi = ((const int32_t *)y)[r0 + rr];
+      float m = z[0];
+      for (int c = 1; c < K; ++c) m = fmaxf(m, z[c]);
+      float se = 0.0f;
+      for (int c = 0; c < K; ++c) se += expf(z[c] - m);
+      v = z[yi] - (m + logf(se));
+    }
+    out_ll[(size_t)(s0 + s) * N + r0 + rr] = v;
+  }
+}

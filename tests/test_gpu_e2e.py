@@ -428,8 +428,8 @@ LPPD_GATE_CASES = [
     (5, (16, 16, 2), 'relu', 'regr', 200, 4, 60, 3.0, 'generic'),
     # BASELINE config B1 (airfoil shape, 3x64 MLP, 16 particles) on the kernel AUTO selects
     (5, (64, 64, 64, 2), 'relu', 'regr', 1052, 16, 120, 1.0, 'mfma_w64_bf16x3'),
-    # the layer-wise GEMM path on a small softmax net (B4's head)
-    (11, (96, 96, 5), 'relu', 'classification', 300, 6, 100, 1.0, 'gemm_f32'),
+    # the layer-wise MFMA GEMM path on a small softmax net (B4's head)
+    (11, (96, 96, 5), 'relu', 'classification', 300, 6, 100, 1.0, 'mfma_wide_bf16x3'),
 ]
 
 
@@ -495,10 +495,10 @@ def test_bf16_kernel_lppd_within_one_percent_of_fp32(oracle):
     (5, (64, 64, 64, 2), 'relu', 'regr', ('mfma_w64', 'mfma_w64_bf16x3', 'generic')),
     (5, (64, 2), 'relu', 'regr', ('mfma_w64', 'generic')),
     (9, (24, 17, 2), 'tanh', 'regr', ('generic',)),
-    (11, (32, 7), 'sigmoid', 'classification', ('generic', 'gemm_f32')),
+    (11, (32, 7), 'sigmoid', 'classification', ('generic', 'gemm_f32', 'mfma_wide_bf16x3')),
     # wide nets evaluate through the strided-batched SGEMM forward (fp32 also when sampling ran on bf16 operands)
-    (9, (128, 128, 128, 2), 'relu', 'regr', ('gemm_f32', 'mfma_w128_bf16')),
-    (54, (256, 256, 7), 'tanh', 'classification', ('gemm_f32',)),
+    (9, (128, 128, 128, 2), 'relu', 'regr', ('gemm_f32', 'mfma_w128_bf16', 'mfma_wide_bf16x3')),
+    (54, (256, 256, 7), 'tanh', 'classification', ('gemm_f32', 'auto')),
 ])
 def test_pointwise_loglik_kernel_matches_oracle(oracle, F, hs, act, task, kernels):
     from mile_amd.metrics import lppd
@@ -662,13 +662,13 @@ def test_full_size_properties_b3(oracle):
 
 def test_full_size_properties_b4(oracle):
     """BASELINE's B4 size (covertype-shaped: N=232404, F=54, [256 x 4, 7] softmax, 128 particles per GPU) on the
-    layer-wise fp32 path, which walks the rows in ~44 chunks here: additivity over data, permutation equivariance
+    layer-wise MFMA path (k_mm3), which walks the rows in chunks here: additivity over data, permutation equivariance
     over particles, generic-kernel agreement on a slice of rows and particles."""
     ospec, N, E = oracle.config_spec('B4')
     prob = oracle.synthetic_problem(ospec, N, E, seed=0)
     th = torch.from_numpy(prob['theta0'])
     ge = _engine(ospec, prob['X'], prob['y'])
-    assert ge.grad_kernel == 'gemm_f32'
+    assert ge.grad_kernel == 'mfma_wide_bf16x3'
     lp1, g1 = ge.logpost_grad(th)
     assert torch.isfinite(lp1).all() and torch.isfinite(g1).all()
     h = 100000
@@ -680,6 +680,7 @@ def test_full_size_properties_b4(oracle):
     assert _rel(lp3.cpu(), lp1.cpu()[perm]) < 1e-6 and _rel(g3.cpu(), g1.cpu()[perm]) < 1e-6
     # the single-launch generic kernel on 3 particles and the first 3000 rows
     sub = slice(0, 3000)
-    r1 = _engine(ospec, prob['X'][sub], prob['y'][sub], 'gemm_f32').logpost_grad(th[:3])
     r2 = _engine(ospec, prob['X'][sub], prob['y'][sub], 'generic').logpost_grad(th[:3])
-    assert _rel(r1[0].cpu(), r2[0].cpu()) < 2e-6 and _rel(r1[1].cpu(), r2[1].cpu()) < 2e-5
+    for k in ('mfma_wide_bf16x3', 'gemm_f32'):          # the MFMA GEMMs, and the rocBLAS cross-check
+        r1 = _engine(ospec, prob['X'][sub], prob['y'][sub], k).logpost_grad(th[:3])
+        assert _rel(r1[0].cpu(), r2[0].cpu()) < 2e-6 and _rel(r1[1].cpu(), r2[1].cpu()) < 2e-5, k

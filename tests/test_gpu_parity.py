@@ -28,15 +28,18 @@ CASES = [
     # in_features, hidden, activation, task, prior, N, E, kernels
     (5, (64, 64, 64, 2), 'relu', 'regr', 'Normal', 1052, 16, ('generic', 'mfma_w64', 'mfma_w64_bf16x3')),
     (5, (64, 64, 64, 2), 'relu', 'regr', 'Normal', 100, 3, ('generic', 'mfma_w64', 'mfma_w64_bf16x3')),
-    (5, (64, 64, 2), 'relu', 'regr', 'Normal', 333, 5, ('generic', 'mfma_w64', 'mfma_w64_bf16x3', 'gemm_f32')),
+    (5, (64, 64, 2), 'relu', 'regr', 'Normal', 333, 5, ('generic', 'mfma_w64', 'mfma_w64_bf16x3', 'gemm_f32', 'mfma_wide_bf16x3')),
     (8, (64, 2), 'relu', 'regr', 'Laplace', 64, 2, ('generic', 'mfma_w64')),
     (5, (16, 16, 2), 'relu', 'regr', 'Normal', 1052, 12, ('generic',)),
-    (9, (24, 17, 2), 'tanh', 'regr', 'Normal', 257, 4, ('generic', 'gemm_f32')),
-    (11, (32, 7), 'sigmoid', 'classification', 'Normal', 500, 6, ('generic', 'gemm_f32')),
-    (54, (40, 40, 7), 'relu', 'classification', 'Laplace', 130, 3, ('generic', 'gemm_f32')),
-    # wide nets: the layer-wise rocBLAS path (what AUTO picks there), B3- and B4-shaped
+    (9, (24, 17, 2), 'tanh', 'regr', 'Normal', 257, 4, ('generic', 'gemm_f32', 'mfma_wide_bf16x3')),
+    (11, (32, 7), 'sigmoid', 'classification', 'Normal', 500, 6, ('generic', 'gemm_f32', 'mfma_wide_bf16x3')),
+    (54, (40, 40, 7), 'relu', 'classification', 'Laplace', 130, 3, ('generic', 'gemm_f32', 'mfma_wide_bf16x3')),
+    # wide nets: the layer-wise paths -- hand-written MFMA GEMMs (what AUTO picks there) and rocBLAS (the cross-check) --
+    # B3- and B4-shaped, and shapes that leave ragged 128 x 128 x 64 tiles in every dimension
     (9, (128, 128, 128, 2), 'relu', 'regr', 'Normal', 700, 6, ('gemm_f32', 'auto')),
-    (54, (256, 256, 256, 256, 7), 'relu', 'classification', 'Normal', 300, 3, ('gemm_f32', 'generic')),
+    (54, (256, 256, 256, 256, 7), 'relu', 'classification', 'Normal', 300, 3, ('gemm_f32', 'generic', 'auto')),
+    (13, (200, 136, 3), 'tanh', 'classification', 'Normal', 1000, 2, ('generic', 'mfma_wide_bf16x3')),
+    (5, (96, 2), 'sigmoid', 'regr', 'Laplace', 129, 1, ('generic', 'mfma_wide_bf16x3')),
     # edge cases: one particle, fewer rows than one MFMA block, ragged last block, one hidden layer,
     # more workgroups than row blocks, F at the padding boundary
     (5, (64, 64, 64, 2), 'relu', 'regr', 'Normal', 2, 1, ('generic', 'mfma_w64', 'mfma_w64_bf16x3')),
@@ -71,7 +74,7 @@ def test_logpost_grad_matches_oracle(oracle, F, hs, act, task, prior, N, E, kern
     lp_ref, g_ref = oracle.logpost_and_grad(ospec, prob['theta0'].astype(np.float64), prob['X'], prob['y'])
     for k in kernels:
         eng = _engine(oracle, ospec, prob, k)
-        assert eng.grad_kernel == (k if k != 'auto' else 'gemm_f32')
+        assert eng.grad_kernel == (k if k != 'auto' else 'mfma_wide_bf16x3')
         lp, g = eng.logpost_grad(torch.from_numpy(prob['theta0']))
         torch.cuda.synchronize()
         # fp32 accumulation over N rows vs fp64: tolerance 2e-5 relative to the largest entry
@@ -149,17 +152,45 @@ def test_bf16_w128_grad_matches_oracle(oracle, F, hs, N, E):
     assert tot.max() < 5e-2, tot.max()
 
 
-def test_gemm_path_row_chunks_accumulate(oracle, monkeypatch):
-    """The layer-wise path walks the data in row chunks when the activation workspace would not hold all of
+@pytest.mark.parametrize('kernel', ['gemm_f32', 'mfma_wide_bf16x3'])
+def test_gemm_path_row_chunks_accumulate(oracle, monkeypatch, kernel):
+    """The layer-wise paths walk the data in row chunks when the activation workspace would not hold all of
     it; force 3 ragged chunks and compare with the oracle."""
     monkeypatch.setenv('MILE_GEMM_ROWS', '100')
     ospec = oracle.ModelSpec(7, (96, 50, 2), activation='tanh')
     prob = oracle.synthetic_problem(ospec, 257, 4, seed=8)
     lp_ref, g_ref = oracle.logpost_and_grad(ospec, prob['theta0'].astype(np.float64), prob['X'], prob['y'])
-    eng = _engine(oracle, ospec, prob, 'gemm_f32')
+    eng = _engine(oracle, ospec, prob, kernel)
     lp, g = eng.logpost_grad(torch.from_numpy(prob['theta0']))
     assert _relerr(lp.cpu().numpy(), lp_ref) < 2e-5
     assert _relerr(g.cpu().numpy(), g_ref) < 2e-5
+
+
+def test_wide_mfma_path_is_fp32_faithful_and_bf16_form_is_close(oracle):
+    """mfma_wide_bf16x3 forms every product from exact three-term bf16 splits (six MFMA products, fp32 accumulation): its
+    error against the fp64 oracle must be fp32-rounding-sized -- no worse than 2x the rocBLAS SGEMM path's (+1e-7 of the
+    largest entry) and an order of magnitude inside the 2e-5 tolerance.  mfma_wide_bf16 (operands rounded to bf16, one
+    product) is the explicit reduced-precision form: a few % of the gradient norm, as for mfma_w128_bf16."""
+    ospec = oracle.ModelSpec(54, (256, 256, 7), task='classification')
+    prob = oracle.synthetic_problem(ospec, 1500, 4, seed=5)
+    lp_ref, g_ref = oracle.logpost_and_grad(ospec, prob['theta0'].astype(np.float64), prob['X'], prob['y'])
+    scale = np.abs(g_ref).max(axis=1, keepdims=True)
+    err = {}
+    for k in ('gemm_f32', 'mfma_wide_bf16x3', 'mfma_wide_bf16'):
+        eng = _engine(oracle, ospec, prob, k)
+        assert eng.grad_kernel == k
+        lp, g = eng.logpost_grad(torch.from_numpy(prob['theta0']))
+        torch.cuda.synchronize()
+        g = g.cpu().numpy().astype(np.float64)
+        err[k] = (np.abs(g - g_ref) / scale).max()
+        if k == 'mfma_wide_bf16':
+            rel = np.linalg.norm(g - g_ref, axis=1) / np.linalg.norm(g_ref, axis=1)
+            assert rel.max() < 5e-2 and _relerr(lp.cpu().numpy(), lp_ref) < 5e-3, (rel.max(),)
+        else:
+            assert _relerr(lp.cpu().numpy(), lp_ref) < 2e-6, k
+    assert err['mfma_wide_bf16x3'] <= 2.0 * err['gemm_f32'] + 1e-7, err
+    assert err['mfma_wide_bf16x3'] < 2e-6, err
+    assert err['mfma_wide_bf16'] > 10 * err['mfma_wide_bf16x3']          # the two forms really differ
 
 
 def test_philox_noise_bits_match_oracle(oracle):

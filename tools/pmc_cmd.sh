@@ -1,0 +1,29 @@
+#!/bin/bash
+# usage (on the GPU box): tools/pmc_cmd.sh <outdir-under-gpurun_out> <python script + args ...>
+# Separate --pmc passes (never combined with trace domains other than kernel-trace); prints per-kernel means.
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA"
+P2="SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_VALU_MFMA_COEXEC_CYCLES"
+P3="GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_LDS SQ_CYCLES SQ_LDS_UNALIGNED_STALL"
+P4="FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum"
+i=1
+for P in "$P1" "$P2" "$P3" "$P4"; do
+  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -- python3 "$@" > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; }
+  i=$((i+1))
+done
+python3 - $OUT <<'PY'
+import sys, glob, csv, collections
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + '/p*/*/*counter_collection.csv'):
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name'].split('(')[0][:60]
+        agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
+for k, cs in agg.items():
+    if 'k_' not in k: continue
+    print(k)
+    for c, v in sorted(cs.items()):
+        print(f'   {c:32s} n={len(v):4d} mean={sum(v)/len(v):16.1f}')
+PY
