@@ -828,20 +828,21 @@ static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t s
 #ifndef MILE_MM_KC
 #define MILE_MM_KC 32     // K chunk of k_mm3: 32 = two workgroups per CU (mile_mm3.h); 64 = one, measured slower
 #endif
-template <int ALAY, int BSRC, int EPI, int TERMS, bool COLSUM = false>
-static hipError_t launch_mm3(const MMParams &p, int batch, hipStream_t st) {
+template <int ALAY, int BSRC, int EPI, int TERMS, int ACT, bool ACCUM, bool COLSUM>
+static hipError_t launch_mm3_k(const MMParams &p, int batch, hipStream_t st) {
   constexpr int KC = MILE_MM_KC;
   using LY = MMLayout<ALAY, BSRC, TERMS, KC>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_mm3<ALAY, BSRC, EPI, TERMS, KC, COLSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, LY::BYTES);
+    hipError_t e = hipFuncSetAttribute((const void *)k_mm3<ALAY, BSRC, EPI, TERMS, KC, ACT, ACCUM, COLSUM>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LY::BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   MMParams q = p;
   const int mtiles = (p.M + 127) / 128;
-  // row tiles per workgroup: as many as keeps >= ~8 workgroups per CU in the grid (tails), at most MILE_MM_TM
-  static const int tm_max = getenv("MILE_MM_TM") ? std::max(1, atoi(getenv("MILE_MM_TM"))) : 1;   // measured on B4: 1 = 434 ms, 4 = 438, 8 = 448 (no gain: not latency-bound)
+  // row tiles per workgroup (cross-tile prefetch): MILE_MM_TM, default 1 -- measured on B4: 1 = 434 ms, 4 = 438, 8 = 448
+  static const int tm_max = getenv("MILE_MM_TM") ? std::max(1, atoi(getenv("MILE_MM_TM"))) : 1;
   int tm = 1;
   if (!COLSUM) {
     const long long wgs = (long long)((p.N + 127) / 128) * mtiles * batch;
@@ -850,8 +851,28 @@ static hipError_t launch_mm3(const MMParams &p, int batch, hipStream_t st) {
   }
   q.tm_per = tm;
   const dim3 grid((p.N + 127) / 128, (mtiles + tm - 1) / tm, batch);
-  k_mm3<ALAY, BSRC, EPI, TERMS, KC, COLSUM><<<grid, 256, LY::BYTES, st>>>(q);
+  k_mm3<ALAY, BSRC, EPI, TERMS, KC, ACT, ACCUM, COLSUM><<<grid, 256, LY::BYTES, st>>>(q);
   return hipGetLastError();
+}
+// the three products of the layer-wise path, dispatched on the launch constants the kernel takes as template parameters
+template <int TERMS>
+static hipError_t launch_mm3_fwd(const MMParams &p, int batch, hipStream_t st) {
+  const int act = p.apply_act ? p.act : -1;
+#define MILE_MM_FWD(A_) launch_mm3_k<MM_A_MK, MM_B_T3_KN, MM_EPI_BIAS_ACT, TERMS, A_, false, false>(p, batch, st)
+  return act == MILE_ACT_RELU ? MILE_MM_FWD(MILE_ACT_RELU) : act == MILE_ACT_TANH ? MILE_MM_FWD(MILE_ACT_TANH)
+       : act == MILE_ACT_SIGMOID ? MILE_MM_FWD(MILE_ACT_SIGMOID) : MILE_MM_FWD(-1);
+#undef MILE_MM_FWD
+}
+template <int TERMS>
+static hipError_t launch_mm3_dh(const MMParams &p, int batch, hipStream_t st) {
+#define MILE_MM_DH(A_) launch_mm3_k<MM_A_MK, MM_B_T3_NK, MM_EPI_ACT_GRAD, TERMS, A_, false, false>(p, batch, st)
+  return p.act == MILE_ACT_RELU ? MILE_MM_DH(MILE_ACT_RELU) : p.act == MILE_ACT_TANH ? MILE_MM_DH(MILE_ACT_TANH) : MILE_MM_DH(MILE_ACT_SIGMOID);
+#undef MILE_MM_DH
+}
+template <int TERMS>
+static hipError_t launch_mm3_dw(const MMParams &p, int batch, hipStream_t st) {
+  return p.accumulate ? launch_mm3_k<MM_A_KM, MM_B_F32_KN, MM_EPI_STORE, TERMS, -1, true, true>(p, batch, st)
+                      : launch_mm3_k<MM_A_KM, MM_B_F32_KN, MM_EPI_STORE, TERMS, -1, false, true>(p, batch, st);
 }
 
 template <int TERMS>
@@ -927,7 +948,7 @@ static int launch_grad_wide(mile_sampler *s, const GradParams &gp, int E, hipStr
       p.M = Rc; p.N = ds.widths[l];
       p.bias = gp.theta + ds.b_off[l]; p.sBias = d;
       p.act = ds.activation; p.apply_act = l + 1 < L;
-      HIP_TRY((launch_mm3<MM_A_MK, MM_B_T3_KN, MM_EPI_BIAS_ACT, TERMS>(p, E, st)));
+      HIP_TRY(launch_mm3_fwd<TERMS>(p, E, st));
     }
     // ---- head: log-likelihood and d(out), in place
     k_wide_head<<<E, 256, 0, st>>>(H[L - 1], (long long)R * wp[L - 1], wp[L - 1], gp.y, r0, Rc, ds.widths[L - 1], ds.task, gp.llpart, chunk == 0);
@@ -944,7 +965,7 @@ static int launch_grad_wide(mile_sampler *s, const GradParams &gp, int E, hipStr
         p.M = fin[l]; p.N = ds.widths[l]; p.K = Rc;
         p.accumulate = chunk != 0;
         p.colsum = slab + ds.b_off[l]; p.sColsum = dp;      // bias gradient dz^T 1 from the B tiles of M tile 0
-        HIP_TRY((launch_mm3<MM_A_KM, MM_B_F32_KN, MM_EPI_STORE, TERMS, true>(p, E, st)));
+        HIP_TRY(launch_mm3_dw<TERMS>(p, E, st));
       }
       if (l > 0) {   // dZ_{l-1} = (dz W_l^T) * act'(H_{l-1})
         MMParams p{};
@@ -954,7 +975,7 @@ static int launch_grad_wide(mile_sampler *s, const GradParams &gp, int E, hipStr
         p.M = Rc; p.N = fin[l];
         p.Hprev = H[l - 1]; p.sH = (long long)R * wp[l - 1]; p.ldh = wp[l - 1];
         p.act = ds.activation;
-        HIP_TRY((launch_mm3<MM_A_MK, MM_B_T3_NK, MM_EPI_ACT_GRAD, TERMS>(p, E, st)));
+        HIP_TRY(launch_mm3_dh<TERMS>(p, E, st));
         dz = tmp[pp];
         pp ^= 1;
       }
@@ -1192,7 +1213,7 @@ static int launch_fwd_wide(mile_sampler *s, const float *theta, int S, const flo
         p.M = Rc; p.N = ds.widths[l];
         p.bias = th + ds.b_off[l]; p.sBias = d;
         p.act = ds.activation; p.apply_act = l + 1 < L;
-        HIP_TRY((launch_mm3<MM_A_MK, MM_B_T3_KN, MM_EPI_BIAS_ACT, 3>(p, Sn, st)));
+        HIP_TRY(launch_mm3_fwd<3>(p, Sn, st));
         pp ^= 1;
       }
       k_wide_rowll<<<dim3((Rc + 255) / 256, Sn), 256, 0, st>>>(buf[pp ^ 1], (long long)R * wp[L - 1], wp[L - 1], y, r0, Rc, ds.widths[L - 1], ds.task, out, N, s0);

@@ -25,6 +25,8 @@
 // grid = (N tiles, M tiles, batch): the batch (particle) index is slowest, so concurrently running workgroups share one
 // particle's weights in L2.
 #pragma once
+#include <type_traits>
+
 #include "mile_bf16_frag.h"
 #include "mile_device.h"
 #include "mile_grad_generic.h"
@@ -95,7 +97,10 @@ struct MMLayout {
 #ifndef MILE_MM_OCC
 #define MILE_MM_OCC 2     // workgroups per CU the register allocation is sized for
 #endif
-template <int ALAY, int BSRC, int EPI, int TERMS, int KC, bool COLSUM = false>
+// ACT (MILE_ACT_* or -1 = none) and ACCUM are template parameters: the epilogue's 64 elements per lane run branch-free
+// (as a per-element run-time switch the epilogue was most of the kernel's instructions; dispatched inside the kernel its
+// eight inlined copies spilled 150 registers).
+template <int ALAY, int BSRC, int EPI, int TERMS, int KC, int ACT, bool ACCUM, bool COLSUM = false>
 __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
   using LY = MMLayout<ALAY, BSRC, TERMS, KC>;
   static_assert(KC == 32 || KC == 64, "K chunk");
@@ -260,22 +265,34 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
         const float *hrow = EPI == MM_EPI_ACT_GRAD ? p.Hprev + (size_t)bz * p.sH + (size_t)mb * p.ldh + n : nullptr;
         const bool full = mb + 28 <= M;                           // all 16 rows of this lane inside the matrix
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int dm = (q & 3) + 8 * (q >> 2);
-          if (!full && mb + dm >= M) continue;
-          float v = acc[a][b][q];
-          if constexpr (EPI == MM_EPI_BIAS_ACT) {
-            v += bias;
-            if (p.apply_act) v = act_fwd(p.act, v);
+        for (int g4 = 0; g4 < 4; ++g4) {                          // four registers at a time: loads first, then arithmetic
+          float hv[4], cv[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int dm = i + 8 * g4;
+            const bool ok = full || mb + dm < M;
+            if constexpr (EPI == MM_EPI_ACT_GRAD) hv[i] = ok ? hrow[(size_t)dm * p.ldh] : 0.0f;
+            if constexpr (ACCUM) cv[i] = ok ? crow[(size_t)dm * p.ldc] : 0.0f;
           }
-          if constexpr (EPI == MM_EPI_ACT_GRAD) v *= act_bwd(p.act, hrow[(size_t)dm * p.ldh]);
-          float *c = crow + (size_t)dm * p.ldc;
-          if (p.accumulate) v += *c;
-          *c = v;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int dm = i + 8 * g4;
+            float v = acc[a][b][4 * g4 + i];
+            if constexpr (EPI == MM_EPI_BIAS_ACT) {
+              v += bias;
+              if constexpr (ACT == MILE_ACT_RELU) v = fmaxf(v, 0.0f);
+              else if constexpr (ACT >= 0) v = act_fwd(ACT, v);
+            }
+            if constexpr (EPI == MM_EPI_ACT_GRAD) {
+              if constexpr (ACT == MILE_ACT_RELU) v = hv[i] > 0.0f ? v : 0.0f;
+              else v *= act_bwd(ACT, hv[i]);
+            }
+            if constexpr (ACCUM) v += cv[i];
+            if (full || mb + dm < M) crow[(size_t)dm * p.ldc] = v;
+          }
         }
       }
   };
-
   const int nk = (K + KC - 1) / KC;
   const int total = ntile_wg * nk;                 // chunks of this workgroup, tile-major
   // software pipeline: the fp32 operands of chunks g+1 .. g+PF are in flight (register stage = chunk % PF) while chunk g is
