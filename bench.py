@@ -53,6 +53,10 @@ WORKLOADS = {
                cpu_particles=16, cpu_seconds=8.0,
                text='B3: protein-shaped N=36000 F=9, FCN hidden_structure [128,128,128,2] relu, Gaussian head, '
                     'StandardNormal prior, d=34562; bf16 matrix operands, fp32 accumulation/parameters/integrator'),
+    'B4': dict(ensemble=128, kernel='auto', dtype='f32', peak=PEAK_FP32_MFMA_TFLOPS, steps=3, warmup=1, cpu_particles=2, cpu_seconds=5.0,
+               text='B4: covertype-shaped N=232404 F=54, FCN hidden_structure [256,256,256,256,7] relu, softmax head, '
+                    'StandardNormal prior, d=213255, 128 particles per GPU (of 1024 over 8); layer-wise MFMA GEMMs (k_mm3), '
+                    'fp32-faithful three-term bf16 products'),
 }
 
 
@@ -173,7 +177,7 @@ class Leg:
         kernel = args.grad_kernel if (args.grad_kernel and name == args.workload) else self.wl['kernel']
         self.prob = prob = oracle.synthetic_problem(self.spec_o, self.N, E * world, seed=0)
         lo, hi = rank * E, (rank + 1) * E
-        self.spec = ModelSpec(self.spec_o.in_features, self.spec_o.hidden_structure, activation='relu', task='regr',
+        self.spec = ModelSpec(self.spec_o.in_features, self.spec_o.hidden_structure, activation='relu', task=self.spec_o.task,
                               prior='StandardNormal')
         self.eng = Engine(self.spec, torch.from_numpy(prob['X']), torch.from_numpy(prob['y']), device=dev, grad_kernel=kernel)
         self.ids = torch.arange(lo, hi, dtype=torch.int32, device=dev)
@@ -266,12 +270,17 @@ class Leg:
             if tj.exists() and self.name == 'B2' and E == WORKLOADS['B2']['ensemble'] and info['kernel'] == 'k_grad_w64':
                 traffic = json.loads(tj.read_text())['hbm_bytes_per_launch']
                 break
-        peak = self.wl['peak'] if eng.grad_kernel == 'mfma_w128_bf16' or self.name == 'B2' else PEAK_FP32_MFMA_TFLOPS
+        peak = self.wl['peak'] if eng.grad_kernel == 'mfma_w128_bf16' or self.name in ('B2', 'B4') else PEAK_FP32_MFMA_TFLOPS
         roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak,
                 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic,
                 'kernel': info['kernel'], 'grid': list(info['grid']), 'lds_bytes': info['lds_bytes'],
                 'avg_launch_us': round(avg_s * 1e6, 2), 'launches_timed': n_launch,
                 'flop_per_launch': flops}
+        if eng.grad_kernel == 'mfma_wide_bf16x3':
+            # every product is six bf16 MFMA products (32 clk per 16-deep chunk) instead of eight fp32 MFMAs of 64 clk
+            roof['mix'] = 'all Dense products as 6 bf16 MFMA products of exact 3-term bf16 splits (fp32-faithful), layer-wise GEMMs'
+            roof['peak_mix_bound'] = round(peak * 8 * 64 / (6 * 32), 1)
+            roof['frac_of_mix_bound'] = round(achieved / (peak * 8 * 64 / (6 * 32)), 4)
         if eng.grad_kernel == 'mfma_w64_bf16x3':
             # `peak` stays the fp32 MFMA peak (the arithmetic is fp32: exact products of 3-term bf16 splits, fp32
             # accumulation).  The kernel's own MFMA-pipe floor is lower than an all-fp32 kernel's: hidden forward /
@@ -291,7 +300,7 @@ class Leg:
         return cpu_baseline(self.spec_o, prob1, self.oracle, self.wl['cpu_seconds'])
 
     def dtype(self):
-        return self.wl['dtype'] if self.eng.grad_kernel == 'mfma_w128_bf16' or self.name == 'B2' else 'f32'
+        return self.wl['dtype'] if self.eng.grad_kernel == 'mfma_w128_bf16' or self.name in ('B2', 'B4') else 'f32'
 
 
 def main():

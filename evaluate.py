@@ -52,7 +52,8 @@ def main():
     # ESS and ESS/s (BASELINE.json's metric; src/inference/metrics.py:386-405 on a parameter subset): per-chain ESS of
     # each selected parameter, summed over chains, min / median over the subset, per second of `time.sampling`
     from mile_amd.metrics import effective_sample_size
-    ok = samples[~bad_chains] if (bad_chains.any() and not bad_chains.all()) else samples
+    fin = np.isfinite(samples).all(axis=(1, 2))             # (samples may already have been filtered by --drop-nonfinite)
+    ok = samples[fin] if (fin.any() and not fin.all()) else samples
     rng = np.random.default_rng(0)
     cols = np.sort(rng.choice(samples.shape[2], size=min(args.ess_params, samples.shape[2]), replace=False))
     if ok.shape[1] >= 8:

@@ -1308,6 +1308,9 @@ int32_t mile_grad_launch_info(const mile_sampler *s, int32_t E, int32_t *grid_x,
   } else if (kernel == MILE_GRAD_LENET_F32) {
     nm = "rocblas_sgemm_strided_batched+k_im2col5/k_col2im5/k_avgpool2";
     lds = 0;
+  } else if (kernel == MILE_GRAD_MFMA_WIDE_BF16X3 || kernel == MILE_GRAD_MFMA_WIDE_BF16) {
+    nm = "k_mm3 (layer-wise MFMA GEMMs)";
+    lds = kernel == MILE_GRAD_MFMA_WIDE_BF16X3 ? MMLayout<MM_A_MK, MM_B_T3_NK, 3, MILE_MM_KC>::BYTES : MMLayout<MM_A_MK, MM_B_T3_NK, 1, MILE_MM_KC>::BYTES;
   } else if (kernel == MILE_GRAD_GEMM_F32) {
     nm = "rocblas_sgemm_strided_batched+k_gemm_*";
     lds = 0;

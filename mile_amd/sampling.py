@@ -110,6 +110,23 @@ def inference_loop(unnorm_log_posterior, config, rng_key, init_params, step_ids,
     leaves = [(n, o, tuple(sh)) for n, o, sh in model.spec.leaves()]
     done = 0
     n_thin = max(int(config.n_thinning), 1)
+    # Kept samples leave the device through two pinned host buffers on a copy stream: the D2H of chunk i runs under the
+    # steps of chunk i+1 and its files are handed to the writers one chunk later -- the stepping stream never waits for
+    # a copy or for the host (the reference blocks the scan on an io_callback per kept sample, sampling.py:140-178).
+    copy_stream = torch.cuda.Stream(device=eng.device)
+    pinned = [None, None]
+    in_flight = None                                   # (event, host buffer view, idxs) of the previous chunk
+
+    def hand_over(job):
+        ev, host_t, idxs = job
+        ev.synchronize()
+        host = host_t.numpy()
+        if return_samples:
+            kept_all.append(host_t.clone())
+        for e, cid in enumerate(step_ids):
+            pool.submit(leaves, np.ascontiguousarray(host[:, e]), str(saving_path), int(cid), idxs)
+
+    slot = 0
     while done < config.n_samples:
         c = min(chunk_steps, config.n_samples - done)
         state, _, samples = eng.step(state, parameters['step_size'], parameters['L'], n_steps=c,
@@ -117,12 +134,24 @@ def inference_loop(unnorm_log_posterior, config, rng_key, init_params, step_ids,
                                      particle_ids=chain_ids, want_info=False, inplace=True)
         if samples is not None:
             idxs = [done + i for i in range(c) if (done + i) % n_thin == 0]
-            host = samples.to('cpu', non_blocking=False).numpy()          # [K, E, d]
-            if return_samples:
-                kept_all.append(torch.from_numpy(host))
-            for e, cid in enumerate(step_ids):
-                pool.submit(leaves, np.ascontiguousarray(host[:, e]), str(saving_path), int(cid), idxs)
+            if pinned[slot] is None or pinned[slot].numel() < samples.numel():
+                pinned[slot] = torch.empty(samples.numel(), dtype=torch.float32, pin_memory=True)
+            host_t = pinned[slot][:samples.numel()].view(samples.shape)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(eng.device))
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(ready)
+                host_t.copy_(samples, non_blocking=True)
+                samples.record_stream(copy_stream)
+                copied = torch.cuda.Event()
+                copied.record(copy_stream)
+            if in_flight is not None:
+                hand_over(in_flight)                   # the previous chunk's copy finished long ago; frees the other buffer
+            in_flight = (copied, host_t, idxs)
+            slot ^= 1
         done += c
+    if in_flight is not None:
+        hand_over(in_flight)
     torch.cuda.synchronize(eng.device)
     t_s1 = time.time()
     n_files = pool.close()
