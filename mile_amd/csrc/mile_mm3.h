@@ -91,8 +91,14 @@ struct MMLayout {
 
 // COLSUM (dW form only: B = dZ as fp32 [K rows][N]): the workgroups of M tile 0 also sum the columns of B over all K rows --
 // the bias gradient dZ^T 1 -- from the B tiles they stage anyway, and write it to p.colsum (fixed order: deterministic).
-#ifndef MILE_MM_PF
-#define MILE_MM_PF 1      // chunks of global loads in flight ahead of the MFMAs (register stages of the fp32 operands)
+// Chunks of global loads in flight ahead of the MFMAs (register stages).  vmcnt retires loads IN ORDER, so every operand
+// stream must have the same depth: a one-deep B stream behind a deeper A stream drains the A loads with it (measured:
+// no gain).  _DW: the dW form (two fp32 streams, 32 registers per stage); _FWD: forward / dH (fp32 A + term-plane B, 40).
+#ifndef MILE_MM_PF_DW
+#define MILE_MM_PF_DW 1
+#endif
+#ifndef MILE_MM_PF_FWD
+#define MILE_MM_PF_FWD 1
 #endif
 #ifndef MILE_MM_OCC
 #define MILE_MM_OCC 2     // workgroups per CU the register allocation is sized for
@@ -120,10 +126,50 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
   const float *A = p.A + (size_t)bz * p.sA;
   float *C = p.C + (size_t)bz * p.sC;
 
+  // ---- loop-invariant LDS byte offsets ---------------------------------------------------------------------------------
+  // img_off(row, ch) = 256 row + 16 (ch ^ swz(row)) and swz depends on row & 15 only, so everything that moves a row by a
+  // multiple of 16 (k-steps, MFMA tiles, passes) or switches the term image is a compile-time constant on top of a handful of
+  // per-lane offsets.  Left to the compiler these were recomputed for every fragment of every chunk: ~150 of the ~380 VALU
+  // instructions per chunk and wave (profiles/r02/05_b4_mm3_pmc_counters.txt), in a kernel where VALU time adds to MFMA time.
+  auto swz = [](int row) { return ((row & 3) << 2) | ((row >> 2) & 3); };
+  constexpr int NKS = KC / 16;
+  // fragments, row-major-K images (A_MK / B_NK): [term][k-step]; MFMA tile q adds 32 rows = 8192 bytes
+  int afr[ALAY == MM_A_MK ? TERMS : 1][NKS], bfr_o[BSRC == MM_B_T3_NK ? TERMS : 1][NKS];
+  // fragments, K-major images (A_KM / B_KN), ds_read_b64_tr_b16: [tile q][first / second 4-row group]; k-step adds 4096, term KC * 256
+  int atr[ALAY == MM_A_KM ? 2 : 1][2], btr[BSRC != MM_B_T3_NK ? 2 : 1][2];
+  {
+    const int g1 = (lane >> 4) & 1, qq = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+    for (int t = 0; t < TERMS; ++t)
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        if constexpr (ALAY == MM_A_MK) afr[t][ks] = mm_rowk_img<KC>(t) + 256 * (64 * wm + r) + 16 * ((mm_rowk_ch<KC>(t) + 2 * ks + h) ^ swz(r & 15));
+        if constexpr (BSRC == MM_B_T3_NK) bfr_o[t][ks] = mm_rowk_img<KC>(t) + 256 * (64 * wn + r) + 16 * ((mm_rowk_ch<KC>(t) + 2 * ks + h) ^ swz(r & 15));
+      }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if constexpr (ALAY == MM_A_KM) {
+        const int ch = ((64 * wm + 32 * q) >> 3) + 2 * g1 + (pp >> 1);
+        atr[q][0] = img_off(8 * h + qq, ch) + 8 * (pp & 1);
+        atr[q][1] = img_off(8 * h + qq + 4, ch) + 8 * (pp & 1);
+      }
+      if constexpr (BSRC != MM_B_T3_NK) {
+        const int ch = ((64 * wn + 32 * q) >> 3) + 2 * g1 + (pp >> 1);
+        btr[q][0] = img_off(8 * h + qq, ch) + 8 * (pp & 1);
+        btr[q][1] = img_off(8 * h + qq + 4, ch) + 8 * (pp & 1);
+      }
+    }
+  }
+  auto tr_read = [&](const char *img, int off0, int off1) {   // the two ds_read_b64_tr_b16 of tr_frag at precomputed offsets
+    const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, img + off0));
+    const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, img + off1));
+    return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+
   // ---- global -> register staging of one K chunk -------------------------------------------------------------------
   // fp32 tiles, one float4 per thread and pass.  [128 rows][KC k]: KC / 4 threads per row; [KC k][128 cols]: 32 per row.
   constexpr int A_TPR = KC / 4, A_NP = ALAY == MM_A_MK ? A_TPR / 2 : KC / 8;
-  constexpr int PF = MILE_MM_PF;
+  constexpr int PF = BSRC == MM_B_F32_KN ? MILE_MM_PF_DW : MILE_MM_PF_FWD;
   f32x4 ra[PF][A_NP];
   auto load_a = [&](const int st, const int m0, int k0) {
     if constexpr (ALAY == MM_A_MK) {
@@ -142,26 +188,27 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
       }
     }
   };
+  // staging stores: [128 rows][KC k] tiles move 256 / A_TPR rows (a multiple of 16) per pass: one offset per term;
+  // [KC k][128] tiles move 8 rows per pass: one offset per pass parity, + 4096 per pair of passes, + KC * 256 per term
+  int aso[ALAY == MM_A_MK ? TERMS : 2];
+  if constexpr (ALAY == MM_A_MK) {
+    const int c4 = tid % A_TPR, r0 = tid / A_TPR;
+#pragma unroll
+    for (int t = 0; t < TERMS; ++t) aso[t] = mm_rowk_img<KC>(t) + 256 * r0 + 16 * ((mm_rowk_ch<KC>(t) + (c4 >> 1)) ^ swz(r0 & 15)) + 8 * (c4 & 1);
+  } else {
+    const int c4 = tid & 31, r0 = tid >> 5;
+#pragma unroll
+    for (int par = 0; par < 2; ++par) aso[par] = img_off(r0 + 8 * par, c4 >> 1) + 8 * (c4 & 1);
+  }
   auto store_a = [&](const int st) {
-    if constexpr (ALAY == MM_A_MK) {
-      const int c4 = tid % A_TPR, r0 = tid / A_TPR;
 #pragma unroll
-      for (int i = 0; i < A_NP; ++i) {
-        mm_u32x2 pk[TERMS];
-        mm_split4<TERMS>(ra[st][i], pk);
+    for (int i = 0; i < A_NP; ++i) {
+      mm_u32x2 pk[TERMS];
+      mm_split4<TERMS>(ra[st][i], pk);
 #pragma unroll
-        for (int t = 0; t < TERMS; ++t)
-          *reinterpret_cast<mm_u32x2 *>(Aimg + mm_rowk_img<KC>(t) + img_off(r0 + (256 / A_TPR) * i, mm_rowk_ch<KC>(t) + (c4 >> 1)) + 8 * (c4 & 1)) = pk[t];
-      }
-    } else {
-      const int c4 = tid & 31, r0 = tid >> 5;
-#pragma unroll
-      for (int i = 0; i < A_NP; ++i) {
-        mm_u32x2 pk[TERMS];
-        mm_split4<TERMS>(ra[st][i], pk);
-#pragma unroll
-        for (int t = 0; t < TERMS; ++t)
-          *reinterpret_cast<mm_u32x2 *>(Aimg + t * KC * 256 + img_off(r0 + 8 * i, c4 >> 1) + 8 * (c4 & 1)) = pk[t];
+      for (int t = 0; t < TERMS; ++t) {
+        if constexpr (ALAY == MM_A_MK) *reinterpret_cast<mm_u32x2 *>(Aimg + aso[t] + 256 * (256 / A_TPR) * i) = pk[t];
+        else *reinterpret_cast<mm_u32x2 *>(Aimg + aso[i & 1] + 4096 * (i >> 1) + t * KC * 256) = pk[t];
       }
     }
   };
@@ -170,7 +217,7 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
   constexpr int BT_NP = KC / 16;                                  // term planes: KN 16 k rows per pass; NK 2048 / KC n rows per pass
   constexpr int NK_CPR = KC / 8;                                  // NK: 16-byte chunks per n row
   f32x4 rb[BSRC == MM_B_F32_KN ? PF : 1][BSRC == MM_B_F32_KN ? BF_NP : 1];
-  mm_u32x4 rbt[BSRC == MM_B_F32_KN ? 1 : TERMS][BT_NP];
+  mm_u32x4 rbt[BSRC == MM_B_F32_KN ? 1 : PF][BSRC == MM_B_F32_KN ? 1 : TERMS][BT_NP];
   float csum[4] = {0.0f, 0.0f, 0.0f, 0.0f};                        // COLSUM: this thread's four columns, its k rows
   auto load_b = [&](const int st, int k0) {
     if constexpr (BSRC == MM_B_F32_KN) {
@@ -189,7 +236,7 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
 #pragma unroll
         for (int i = 0; i < BT_NP; ++i) {
           const int k = k0 + r0 + 16 * i, n = n0 + 8 * c;
-          rbt[t][i] = (k < K && n < N) ? *(const mm_u32x4 *)(B + (size_t)t * p.tB + (size_t)k * p.ldb + n) : mm_u32x4{0, 0, 0, 0};
+          rbt[st][t][i] = (k < K && n < N) ? *(const mm_u32x4 *)(B + (size_t)t * p.tB + (size_t)k * p.ldb + n) : mm_u32x4{0, 0, 0, 0};
         }
     } else {
       const bf16 *B = (const bf16 *)p.B + (size_t)bz * p.sB;
@@ -199,13 +246,24 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
 #pragma unroll
         for (int i = 0; i < BT_NP; ++i) {
           const int n = n0 + r0 + (256 / NK_CPR) * i, k = k0 + 8 * c;
-          rbt[t][i] = (n < N && k < K) ? *(const mm_u32x4 *)(B + (size_t)t * p.tB + (size_t)n * p.ldb + k) : mm_u32x4{0, 0, 0, 0};
+          rbt[st][t][i] = (n < N && k < K) ? *(const mm_u32x4 *)(B + (size_t)t * p.tB + (size_t)n * p.ldb + k) : mm_u32x4{0, 0, 0, 0};
         }
     }
   };
+  int bso[BSRC == MM_B_T3_NK ? TERMS : 2];
+  if constexpr (BSRC == MM_B_F32_KN) {
+    const int c4 = tid & 31, r0 = tid >> 5;
+#pragma unroll
+    for (int par = 0; par < 2; ++par) bso[par] = img_off(r0 + 8 * par, c4 >> 1) + 8 * (c4 & 1);
+  } else if constexpr (BSRC == MM_B_T3_KN) {
+    bso[0] = img_off(tid >> 4, tid & 15); bso[1] = 0;                  // rows r0 + 16 i: + 4096 i
+  } else {
+    const int c = tid % NK_CPR, r0 = tid / NK_CPR;
+#pragma unroll
+    for (int t = 0; t < TERMS; ++t) bso[t] = mm_rowk_img<KC>(t) + 256 * r0 + 16 * ((mm_rowk_ch<KC>(t) + c) ^ swz(r0 & 15));
+  }
   auto store_b = [&](const int st) {
     if constexpr (BSRC == MM_B_F32_KN) {
-      const int c4 = tid & 31, r0 = tid >> 5;
 #pragma unroll
       for (int i = 0; i < BF_NP; ++i) {
         if constexpr (COLSUM) {
@@ -215,22 +273,18 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
         mm_u32x2 pk[TERMS];
         mm_split4<TERMS>(rb[st][i], pk);
 #pragma unroll
-        for (int t = 0; t < TERMS; ++t)
-          *reinterpret_cast<mm_u32x2 *>(Bimg + t * KC * 256 + img_off(r0 + 8 * i, c4 >> 1) + 8 * (c4 & 1)) = pk[t];
+        for (int t = 0; t < TERMS; ++t) *reinterpret_cast<mm_u32x2 *>(Bimg + bso[i & 1] + 4096 * (i >> 1) + t * KC * 256) = pk[t];
       }
     } else if constexpr (BSRC == MM_B_T3_KN) {
-      const int c = tid & 15, r0 = tid >> 4;
 #pragma unroll
       for (int t = 0; t < TERMS; ++t)
 #pragma unroll
-        for (int i = 0; i < BT_NP; ++i) *reinterpret_cast<mm_u32x4 *>(Bimg + t * KC * 256 + img_off(r0 + 16 * i, c)) = rbt[t][i];
+        for (int i = 0; i < BT_NP; ++i) *reinterpret_cast<mm_u32x4 *>(Bimg + bso[0] + 4096 * i + t * KC * 256) = rbt[st][t][i];
     } else {
-      const int c = tid % NK_CPR, r0 = tid / NK_CPR;
 #pragma unroll
       for (int t = 0; t < TERMS; ++t)
 #pragma unroll
-        for (int i = 0; i < BT_NP; ++i)
-          *reinterpret_cast<mm_u32x4 *>(Bimg + mm_rowk_img<KC>(t) + img_off(r0 + (256 / NK_CPR) * i, mm_rowk_ch<KC>(t) + c)) = rbt[t][i];
+        for (int i = 0; i < BT_NP; ++i) *reinterpret_cast<mm_u32x4 *>(Bimg + bso[t] + 256 * (256 / NK_CPR) * i) = rbt[st][t][i];
     }
   };
 
@@ -297,14 +351,13 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
   const int total = ntile_wg * nk;                 // chunks of this workgroup, tile-major
   // software pipeline: the fp32 operands of chunks g+1 .. g+PF are in flight (register stage = chunk % PF) while chunk g is
   // multiplied; pre-split weight planes (L2-resident) stay one chunk ahead.  Chunk g = (tile g / nk, K chunk g % nk).
-  constexpr bool B_DEEP = BSRC == MM_B_F32_KN;
   auto chunk_m0 = [&](int g) { return (mt_first + g / nk) * 128; };
   auto chunk_k0 = [&](int g) { return KC * (g % nk); };
 #pragma unroll
   for (int j = 0; j < PF; ++j)
     if (j < total) {
       load_a(j, chunk_m0(j), chunk_k0(j));
-      if (B_DEEP || j == 0) load_b(B_DEEP ? j : 0, chunk_k0(j));
+      load_b(j, chunk_k0(j));
     }
   for (int g0 = 0; g0 < total; g0 += PF)
 #pragma unroll
@@ -318,11 +371,12 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
     }
     __syncthreads();          // every wave has read the previous chunk's images
     store_a(j);
-    store_b(B_DEEP ? j : 0);
+    store_b(j);
     __syncthreads();
-    if (g + PF < total) load_a(j, chunk_m0(g + PF), chunk_k0(g + PF));       // refill this stage
-    if (B_DEEP) { if (g + PF < total) load_b(j, chunk_k0(g + PF)); }
-    else if (g + 1 < total) load_b(0, chunk_k0(g + 1));
+    if (g + PF < total) {     // refill this stage: both streams, same depth (in-order vmcnt)
+      load_a(j, chunk_m0(g + PF), chunk_k0(g + PF));
+      load_b(j, chunk_k0(g + PF));
+    }
     const int ksteps = min(KC / 16, (K - KC * kc + 15) / 16);
     auto kstep = [&](const int ks) {
       bf16x8 af[2][TERMS], bfr[2][TERMS];
@@ -330,10 +384,10 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
       for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int t = 0; t < TERMS; ++t) {
-          if constexpr (ALAY == MM_A_MK) af[q][t] = row_frag(Aimg + mm_rowk_img<KC>(t), 64 * wm + 32 * q + r, mm_rowk_ch<KC>(t) + 2 * ks + h);
-          else af[q][t] = tr_frag(Aimg + t * KC * 256, 16 * ks, 64 * wm + 32 * q, lane);
-          if constexpr (BSRC == MM_B_T3_NK) bfr[q][t] = row_frag(Bimg + mm_rowk_img<KC>(t), 64 * wn + 32 * q + r, mm_rowk_ch<KC>(t) + 2 * ks + h);
-          else bfr[q][t] = tr_frag(Bimg + t * KC * 256, 16 * ks, 64 * wn + 32 * q, lane);
+          if constexpr (ALAY == MM_A_MK) af[q][t] = *reinterpret_cast<const bf16x8 *>(Aimg + afr[t][ks] + 8192 * q);
+          else af[q][t] = tr_read(Aimg + t * KC * 256 + 4096 * ks, atr[q][0], atr[q][1]);
+          if constexpr (BSRC == MM_B_T3_NK) bfr[q][t] = *reinterpret_cast<const bf16x8 *>(Bimg + bfr_o[t][ks] + 8192 * q);
+          else bfr[q][t] = tr_read(Bimg + t * KC * 256 + 4096 * ks, btr[q][0], btr[q][1]);
         }
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -350,11 +404,10 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
           acc[a][b] = mfma_bf16(af[a][0], bfr[b][0], acc[a][b]);
         }
     };
-    if (ksteps == KC / 16) {  // full chunk: constant image offsets
 #pragma unroll
-      for (int ks = 0; ks < KC / 16; ++ks) kstep(ks);
-    } else {
-      for (int ks = 0; ks < ksteps; ++ks) kstep(ks);
+    for (int ks = 0; ks < NKS; ++ks) {   // one k-step's fragments live at a time; a ragged last chunk skips the empty k-steps
+      if (ks < ksteps) kstep(ks);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (kc == nk - 1) {       // this C tile is complete (the next tile's first chunk is already in flight)
       epilogue(m0);
