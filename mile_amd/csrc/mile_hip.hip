@@ -841,17 +841,30 @@ static hipError_t launch_mm3_k(const MMParams &p, int batch, hipStream_t st) {
   }
   MMParams q = p;
   const int mtiles = (p.M + 127) / 128;
-  // row tiles per workgroup (cross-tile prefetch): MILE_MM_TM, default 1 -- measured on B4: 1 = 434 ms, 4 = 438, 8 = 448
-  static const int tm_max = getenv("MILE_MM_TM") ? std::max(1, atoi(getenv("MILE_MM_TM"))) : 1;
-  int tm = 1;
-  if (!COLSUM) {
-    const long long wgs = (long long)((p.N + 127) / 128) * mtiles * batch;
-    tm = (int)std::max<long long>(1, std::min<long long>(tm_max, wgs / (256 * 2 * 8)));
-    tm = std::min(tm, mtiles);
+  const dim3 grid((p.N + 127) / 128, mtiles, batch);
+  q.c_vec = (p.ldc % 4 == 0) && (p.sC % 4 == 0) && (((uintptr_t)p.C & 15) == 0);
+  static const bool no_remap = getenv("MILE_MM_NO_XCD") != nullptr;
+  q.xcd_remap = 0;
+  if (!no_remap) {
+    if (COLSUM && batch % 8 == 0) q.xcd_remap = 2;                     // dW: the few tiles of a particle share both operands
+    else if (!COLSUM && grid.x > 1 && grid.y >= 8) q.xcd_remap = 1;
   }
-  q.tm_per = tm;
-  const dim3 grid((p.N + 127) / 128, (mtiles + tm - 1) / tm, batch);
+  static const bool dbg = getenv("MILE_DEBUG") && (atoi(getenv("MILE_DEBUG")) & 64);
+  static unsigned long long *dbuf = nullptr;
+  if (dbg) {   // dev: mean time per phase of wave 0 (100 MHz ticks -> us), per launch
+    if (!dbuf && hipMalloc(&dbuf, 64) != hipSuccess) return hipErrorOutOfMemory;
+    (void)hipMemsetAsync(dbuf, 0, 64, st);
+    q.dbg = dbuf;
+  }
   k_mm3<ALAY, BSRC, EPI, TERMS, KC, ACT, ACCUM, COLSUM><<<grid, 256, LY::BYTES, st>>>(q);
+  if (dbg) {
+    unsigned long long h[8];
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h, dbuf, 64, hipMemcpyDeviceToHost);
+    const double nc = (double)std::max<unsigned long long>(h[5], 1), nt = (double)std::max<unsigned long long>(h[6], 1);
+    fprintf(stderr, "k_mm3<A%d,B%d,E%d> M=%d N=%d K=%d grid %ux%ux%u: per chunk us: wait loads+barrier %.2f  split+store %.2f  barrier %.2f  loads issue+frags+MFMA %.2f | per tile: epilogue %.2f  (chunks/tile %.1f)\n",
+            ALAY, BSRC, EPI, p.M, p.N, p.K, grid.x, grid.y, grid.z, h[0] / nc * 0.01, h[1] / nc * 0.01, h[2] / nc * 0.01, h[3] / nc * 0.01, h[4] / nt * 0.01, nc / nt);
+  }
   return hipGetLastError();
 }
 // the three products of the layer-wise path, dispatched on the launch constants the kernel takes as template parameters

@@ -45,7 +45,9 @@ struct MMParams {
   const float *Hprev; long long sH; int ldh; // MM_EPI_ACT_GRAD: activation OUTPUT whose derivative multiplies C
   int act, apply_act, accumulate;            // accumulate: C += (row chunks of dW)
   float *colsum; long long sColsum;          // COLSUM: column sums of B over K -> colsum[bz * sColsum + n] (any alignment)
-  int tm_per;                                // consecutive 128-row C tiles per workgroup (>= 1; 1 when COLSUM)
+  int c_vec;                                 // C (and the accumulate reads of it) may use 16-byte accesses: ldc % 4 == 0, base aligned
+  int xcd_remap;                             // 0 none; 1 N tiles of a row tile share an XCD; 2 all tiles of a batch entry do
+  unsigned long long *dbg;                   // dev (MILE_DEBUG=64): per-phase 100 MHz tick sums of wave 0 of every workgroup
 };
 
 typedef uint32_t mm_u32x2 __attribute__((ext_vector_type(2)));
@@ -86,7 +88,8 @@ template <int ALAY, int BSRC, int TERMS, int KC>
 struct MMLayout {
   static constexpr int A_BYTES = ALAY == MM_A_MK ? mm_rowk_bytes<TERMS, KC>() : mm_kmaj_bytes<TERMS, KC>();
   static constexpr int B_BYTES = BSRC == MM_B_T3_NK ? mm_rowk_bytes<TERMS, KC>() : mm_kmaj_bytes<TERMS, KC>();
-  static constexpr int BYTES = A_BYTES + B_BYTES;
+  static constexpr int STAGE_BYTES = 4 * 32 * 68 * 4;   // the epilogue's per-wave [32][68] fp32 staging, aliasing the images
+  static constexpr int BYTES = A_BYTES + B_BYTES > STAGE_BYTES ? A_BYTES + B_BYTES : STAGE_BYTES;
 };
 
 // COLSUM (dW form only: B = dZ as fp32 [K rows][N]): the workgroups of M tile 0 also sum the columns of B over all K rows --
@@ -116,12 +119,38 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const int bz = blockIdx.z, n0 = blockIdx.x * 128;
-  // a workgroup walks p.tm_per consecutive 128-row tiles of C (same columns, same batch entry) as ONE software pipeline:
-  // the first chunk of the next tile is in flight under the last MFMAs and the epilogue of the current one (with K = 256
-  // a tile is only 8 chunks: loading its first chunk cold and draining its stores would otherwise dominate)
-  const int mtiles = (p.M + 127) / 128, mt_first = blockIdx.y * p.tm_per;
-  const int ntile_wg = min(p.tm_per, mtiles - mt_first);
+  // XCD-aware placement (speed only): workgroups are dealt round-robin over the 8 XCDs by linear id, each XCD has its own L2.
+  // The workgroups that read the SAME operand chunk -- the N tiles of one (M tile, batch entry), and for the dW form all
+  // tiles of a batch entry -- get linear ids 8 apart, so the second reader hits the first one's L2 lines instead of HBM.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.xcd_remap) {
+    const int nx = gridDim.x, ny = gridDim.y, nz = gridDim.z;
+    const long long lin = (long long)blockIdx.x + (long long)nx * (blockIdx.y + (long long)ny * blockIdx.z);
+    if (p.xcd_remap == 2) {            // all nx * ny tiles of a batch entry on one XCD (nz % 8 == 0)
+      const int per = nx * ny;
+      const long long grp = lin / (8LL * per);
+      const int rem = (int)(lin % (8LL * per));
+      bz = (int)(grp * 8) + (rem & 7);
+      const int t = rem >> 3;
+      bx = t % nx; by = t / nx;
+    } else {                           // the nx N tiles of an (M tile, batch entry) on one XCD
+      const long long plane = lin / ((long long)nx * ny);
+      const int rem = (int)(lin % ((long long)nx * ny));
+      const int nfull = ny / 8 * 8;    // M tiles beyond the last full group of 8 keep the plain order
+      bz = (int)plane;
+      if (rem < nfull * nx) {
+        const int grp = rem / (8 * nx), r8 = rem % (8 * nx);
+        by = grp * 8 + (r8 & 7);
+        bx = r8 >> 3;
+      } else {
+        const int t = rem - nfull * nx;
+        by = nfull + t / nx;
+        bx = t % nx;
+      }
+    }
+  }
+  const int n0 = bx * 128;
+  const int m0 = by * 128;
   const int M = p.M, N = p.N, K = p.K;
   const float *A = p.A + (size_t)bz * p.sA;
   float *C = p.C + (size_t)bz * p.sC;
@@ -171,21 +200,37 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
   constexpr int A_TPR = KC / 4, A_NP = ALAY == MM_A_MK ? A_TPR / 2 : KC / 8;
   constexpr int PF = BSRC == MM_B_F32_KN ? MILE_MM_PF_DW : MILE_MM_PF_FWD;
   f32x4 ra[PF][A_NP];
-  auto load_a = [&](const int st, const int m0, int k0) {
-    if constexpr (ALAY == MM_A_MK) {
-      const int c4 = tid % A_TPR, r0 = tid / A_TPR;
+  // Global operand loads are raw buffer loads: a per-thread byte offset fixed for the whole workgroup (rows / columns outside
+  // the matrix get an out-of-range offset and read as zero) + a SCALAR offset that walks K -- no per-load 64-bit address
+  // arithmetic or predicates in the K loop (they were ~100 of the VALU instructions per chunk and wave).  Only a ragged last
+  // chunk (K % KC != 0) pays a select per load.
+  constexpr int MM_OOB = 0x7ffffff0;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(A), 0, (int)min((long long)(ALAY == MM_A_MK ? M : K) * p.lda * 4, 0x7fffffffLL), 0x00020000);
+  int voa[A_NP];
+  if constexpr (ALAY == MM_A_MK) {
+    const int c4 = tid % A_TPR, r0 = tid / A_TPR;
 #pragma unroll
-      for (int i = 0; i < A_NP; ++i) {
-        const int m = m0 + r0 + (256 / A_TPR) * i, k = k0 + 4 * c4;
-        ra[st][i] = (m < M && k < K) ? *(const f32x4 *)(A + (size_t)m * p.lda + k) : f32x4{0, 0, 0, 0};
-      }
-    } else {
-      const int c4 = tid & 31, r0 = tid >> 5;
+    for (int i = 0; i < A_NP; ++i) {
+      const int m = m0 + r0 + (256 / A_TPR) * i;
+      voa[i] = m < M ? (m * p.lda + 4 * c4) * 4 : MM_OOB;
+    }
+  } else {
+    const int c4 = tid & 31, r0 = tid >> 5;
 #pragma unroll
-      for (int i = 0; i < A_NP; ++i) {
-        const int k = k0 + r0 + 8 * i, m = m0 + 4 * c4;
-        ra[st][i] = (k < K && m < M) ? *(const f32x4 *)(A + (size_t)k * p.lda + m) : f32x4{0, 0, 0, 0};
+    for (int i = 0; i < A_NP; ++i) voa[i] = m0 + 4 * c4 < M ? ((r0 + 8 * i) * p.lda + m0 + 4 * c4) * 4 : MM_OOB;
+  }
+  auto load_a = [&](const int st, const int k0) {
+    const int so = ALAY == MM_A_MK ? k0 * 4 : k0 * p.lda * 4;
+    const bool ragged = k0 + KC > K;
+#pragma unroll
+    for (int i = 0; i < A_NP; ++i) {
+      int vo = voa[i];
+      if (ragged) {
+        const bool ok = ALAY == MM_A_MK ? k0 + 4 * (tid % A_TPR) < K : k0 + (tid >> 5) + 8 * i < K;
+        vo = ok ? vo : MM_OOB;
       }
+      ra[st][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, so, 0));
     }
   };
   // staging stores: [128 rows][KC k] tiles move 256 / A_TPR rows (a multiple of 16) per pass: one offset per term;
@@ -219,35 +264,51 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
   f32x4 rb[BSRC == MM_B_F32_KN ? PF : 1][BSRC == MM_B_F32_KN ? BF_NP : 1];
   mm_u32x4 rbt[BSRC == MM_B_F32_KN ? 1 : PF][BSRC == MM_B_F32_KN ? 1 : TERMS][BT_NP];
   float csum[4] = {0.0f, 0.0f, 0.0f, 0.0f};                        // COLSUM: this thread's four columns, its k rows
-  auto load_b = [&](const int st, int k0) {
+  const void *Bb = BSRC == MM_B_F32_KN ? (const void *)((const float *)p.B + (size_t)bz * p.sB) : (const void *)((const bf16 *)p.B + (size_t)bz * p.sB);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void *>(Bb), 0, (int)min(BSRC == MM_B_F32_KN ? (long long)K * p.ldb * 4 : (long long)TERMS * p.tB * 2, 0x7fffffffLL), 0x00020000);
+  constexpr int B_NP = BSRC == MM_B_F32_KN ? BF_NP : BT_NP;
+  int vob[B_NP];
+  if constexpr (BSRC == MM_B_F32_KN) {
+    const int c4 = tid & 31, r0 = tid >> 5;
+#pragma unroll
+    for (int i = 0; i < B_NP; ++i) vob[i] = n0 + 4 * c4 < N ? ((r0 + 8 * i) * p.ldb + n0 + 4 * c4) * 4 : MM_OOB;
+  } else if constexpr (BSRC == MM_B_T3_KN) {
+    const int c = tid & 15, r0 = tid >> 4;            // [KC k][128 n]: 16 chunks of 8 columns per row
+#pragma unroll
+    for (int i = 0; i < B_NP; ++i) vob[i] = n0 + 8 * c < N ? ((r0 + 16 * i) * p.ldb + n0 + 8 * c) * 2 : MM_OOB;
+  } else {
+    const int c = tid % NK_CPR, r0 = tid / NK_CPR;    // [128 n][KC k]: KC / 8 chunks of 8 k per row
+#pragma unroll
+    for (int i = 0; i < B_NP; ++i) {
+      const int n = n0 + r0 + (256 / NK_CPR) * i;
+      vob[i] = n < N ? (n * p.ldb + 8 * c) * 2 : MM_OOB;
+    }
+  }
+  auto load_b = [&](const int st, const int k0) {
+    const bool ragged = k0 + KC > K;
     if constexpr (BSRC == MM_B_F32_KN) {
-      const float *B = (const float *)p.B + (size_t)bz * p.sB;
-      const int c4 = tid & 31, r0 = tid >> 5;
+      const int so = k0 * p.ldb * 4;
 #pragma unroll
-      for (int i = 0; i < BF_NP; ++i) {
-        const int k = k0 + r0 + 8 * i, n = n0 + 4 * c4;
-        rb[st][i] = (k < K && n < N) ? *(const f32x4 *)(B + (size_t)k * p.ldb + n) : f32x4{0, 0, 0, 0};
+      for (int i = 0; i < B_NP; ++i) {
+        int vo = vob[i];
+        if (ragged) vo = k0 + (tid >> 5) + 8 * i < K ? vo : MM_OOB;
+        rb[st][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, vo, so, 0));
       }
-    } else if constexpr (BSRC == MM_B_T3_KN) {
-      const bf16 *B = (const bf16 *)p.B + (size_t)bz * p.sB;
-      const int c = tid & 15, r0 = tid >> 4;          // [KC k][128 n]: 16 chunks of 8 columns per row
-#pragma unroll
-      for (int t = 0; t < TERMS; ++t)
-#pragma unroll
-        for (int i = 0; i < BT_NP; ++i) {
-          const int k = k0 + r0 + 16 * i, n = n0 + 8 * c;
-          rbt[st][t][i] = (k < K && n < N) ? *(const mm_u32x4 *)(B + (size_t)t * p.tB + (size_t)k * p.ldb + n) : mm_u32x4{0, 0, 0, 0};
-        }
     } else {
-      const bf16 *B = (const bf16 *)p.B + (size_t)bz * p.sB;
-      const int c = tid % NK_CPR, r0 = tid / NK_CPR;  // [128 n][KC k]: KC / 8 chunks of 8 k per row
 #pragma unroll
-      for (int t = 0; t < TERMS; ++t)
+      for (int t = 0; t < TERMS; ++t) {
+        const int so = BSRC == MM_B_T3_KN ? (int)((t * p.tB + (long long)k0 * p.ldb) * 2) : (int)((t * p.tB + k0) * 2);
 #pragma unroll
-        for (int i = 0; i < BT_NP; ++i) {
-          const int n = n0 + r0 + (256 / NK_CPR) * i, k = k0 + 8 * c;
-          rbt[st][t][i] = (n < N && k < K) ? *(const mm_u32x4 *)(B + (size_t)t * p.tB + (size_t)n * p.ldb + k) : mm_u32x4{0, 0, 0, 0};
+        for (int i = 0; i < B_NP; ++i) {
+          int vo = vob[i];
+          if (ragged) {
+            const bool ok = BSRC == MM_B_T3_KN ? k0 + (tid >> 4) + 16 * i < K : k0 + 8 * (tid % NK_CPR) < K;
+            vo = ok ? vo : MM_OOB;
+          }
+          rbt[st][t][i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, vo, so, 0);
         }
+      }
     }
   };
   int bso[BSRC == MM_B_T3_NK ? TERMS : 2];
@@ -304,78 +365,119 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
   for (int q = 0; q < 2; ++q) nt_on[q] = n0 + 64 * wn + 32 * q < N;
 
   // ---- epilogue of one C tile: D[m = acc_m(reg, h)][n = r] per 32 x 32 MFMA tile ---------------------------------------
+  // The wave's 64 x 64 quadrant goes through LDS in two 32-row halves ([32][68] floats = 8.7 KB per wave, aliasing the operand
+  // images) so that EVERY global access of the epilogue is a 16-byte one: with 4-byte accesses in the accumulator layout the
+  // C stores cost 73 ms and the dH form's H_{l-1} reads 82 ms of a 409 ms B4 gradient (MILE_MM_SKIP knobs,
+  // profiles/r02/05_b4_mm3_pmc_counters.txt) -- four times the memory instructions, and the reads were 16 dependent round trips.
   auto epilogue = [&](const int m0) {
+    __syncthreads();                                            // every wave has finished reading the operand images
+    float *stage = reinterpret_cast<float *>(mm_smem) + wave * (32 * 68);
+    const int c4 = lane & 15, rr = lane >> 4;                   // this lane's float4 column (of 16) and row within a group of 4
+    const int nq = n0 + 64 * wn + 4 * c4;                       // first of its four columns
+    float bias4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if constexpr (EPI == MM_EPI_BIAS_ACT) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+      for (int c = 0; c < 4; ++c)
+        if (nq + c < N) bias4[c] = p.bias[(size_t)bz * p.sBias + nq + c];
+    }
+    const bool vec_ok = nq + 3 < N && p.c_vec;                  // whole float4 inside the matrix and 16-byte aligned
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        if (!(mt_on[a] && nt_on[b])) continue;
-        const int n = n0 + 64 * wn + 32 * b + r;
-        if (n >= N) continue;
-        float bias = 0.0f;
-        if constexpr (EPI == MM_EPI_BIAS_ACT) bias = p.bias[(size_t)bz * p.sBias + n];
-        const int mb = m0 + 64 * wm + 32 * a + 4 * h;            // row of register q: mb + (q & 3) + 8 (q >> 2)
-        float *crow = C + (size_t)mb * p.ldc + n;
-        const float *hrow = EPI == MM_EPI_ACT_GRAD ? p.Hprev + (size_t)bz * p.sH + (size_t)mb * p.ldh + n : nullptr;
-        const bool full = mb + 28 <= M;                           // all 16 rows of this lane inside the matrix
+    for (int a = 0; a < 2; ++a) {
+      if (!mt_on[a]) continue;                                  // wave-uniform
+      const int mr0 = m0 + 64 * wm + 32 * a;
+      f32x4 hv[8], cv[8];
+      if constexpr (EPI == MM_EPI_ACT_GRAD) {                   // all reads of the half tile in flight before anything waits
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {                          // four registers at a time: loads first, then arithmetic
-          float hv[4], cv[4];
+        for (int i = 0; i < 8; ++i) {
+          const int m = mr0 + rr + 4 * i;
+          hv[i] = (m < M && nq < N) ? *(const f32x4 *)(p.Hprev + (size_t)bz * p.sH + (size_t)m * p.ldh + nq)
+                                                         : f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+        }
+      }
+      if constexpr (ACCUM) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int dm = i + 8 * g4;
-            const bool ok = full || mb + dm < M;
-            if constexpr (EPI == MM_EPI_ACT_GRAD) hv[i] = ok ? hrow[(size_t)dm * p.ldh] : 0.0f;
-            if constexpr (ACCUM) cv[i] = ok ? crow[(size_t)dm * p.ldc] : 0.0f;
-          }
+        for (int i = 0; i < 8; ++i) {
+          const int m = mr0 + rr + 4 * i;
+          const float *c = C + (size_t)m * p.ldc + nq;
+          cv[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+          if (m < M) {
+            if (vec_ok) cv[i] = *(const f32x4 *)c;
+            else {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int dm = i + 8 * g4;
-            float v = acc[a][b][4 * g4 + i];
-            if constexpr (EPI == MM_EPI_BIAS_ACT) {
-              v += bias;
-              if constexpr (ACT == MILE_ACT_RELU) v = fmaxf(v, 0.0f);
-              else if constexpr (ACT >= 0) v = act_fwd(ACT, v);
+              for (int cc = 0; cc < 4; ++cc)
+                if (nq + cc < N) cv[i][cc] = c[cc];
             }
-            if constexpr (EPI == MM_EPI_ACT_GRAD) {
-              if constexpr (ACT == MILE_ACT_RELU) v = hv[i] > 0.0f ? v : 0.0f;
-              else v *= act_bwd(ACT, hv[i]);
-            }
-            if constexpr (ACCUM) v += cv[i];
-            if (full || mb + dm < M) crow[(size_t)dm * p.ldc] = v;
           }
         }
       }
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) stage[(4 * h + (q & 3) + 8 * (q >> 2)) * 68 + 32 * b + r] = acc[a][b][q];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    // wave-private region: LDS ops of one wave execute in order
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int m = mr0 + rr + 4 * i;
+        f32x4 v = *(const f32x4 *)(stage + (rr + 4 * i) * 68 + 4 * c4);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          float x = v[cc];
+          if constexpr (EPI == MM_EPI_BIAS_ACT) {
+            x += bias4[cc];
+            if constexpr (ACT == MILE_ACT_RELU) x = fmaxf(x, 0.0f);
+            else if constexpr (ACT >= 0) x = act_fwd(ACT, x);
+          }
+          if constexpr (EPI == MM_EPI_ACT_GRAD) {
+            if constexpr (ACT == MILE_ACT_RELU) x = hv[i][cc] > 0.0f ? x : 0.0f;
+            else x *= act_bwd(ACT, hv[i][cc]);
+          }
+          if constexpr (ACCUM) x += cv[i][cc];
+          v[cc] = x;
+        }
+        if (m < M) {
+          float *c = C + (size_t)m * p.ldc + nq;
+          if (vec_ok) *(f32x4 *)c = v;
+          else {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+              if (nq + cc < N) c[cc] = v[cc];
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
   };
   const int nk = (K + KC - 1) / KC;
-  const int total = ntile_wg * nk;                 // chunks of this workgroup, tile-major
-  // software pipeline: the fp32 operands of chunks g+1 .. g+PF are in flight (register stage = chunk % PF) while chunk g is
-  // multiplied; pre-split weight planes (L2-resident) stay one chunk ahead.  Chunk g = (tile g / nk, K chunk g % nk).
-  auto chunk_m0 = [&](int g) { return (mt_first + g / nk) * 128; };
-  auto chunk_k0 = [&](int g) { return KC * (g % nk); };
+  // software pipeline: the operands of chunks kc+1 .. kc+PF are in flight (register stage = chunk % PF) while chunk kc is
+  // multiplied; both streams the same depth (vmcnt retires in order)
 #pragma unroll
   for (int j = 0; j < PF; ++j)
-    if (j < total) {
-      load_a(j, chunk_m0(j), chunk_k0(j));
-      load_b(j, chunk_k0(j));
+    if (j < nk) {
+      load_a(j, KC * j);
+      load_b(j, KC * j);
     }
-  for (int g0 = 0; g0 < total; g0 += PF)
+#pragma unroll
+  for (int q = 0; q < 2; ++q) mt_on[q] = m0 + 64 * wm + 32 * q < M;
+  for (int g0 = 0; g0 < nk; g0 += PF)
 #pragma unroll
   for (int j = 0; j < PF; ++j) {
-    const int g = g0 + j;
-    if (g >= total) break;
-    const int kc = g % nk, m0 = chunk_m0(g);
-    if (kc == 0) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) mt_on[q] = m0 + 64 * wm + 32 * q < M;
-    }
+    const int kc = g0 + j;
+    if (kc >= nk) break;
+    long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
+    const bool stampw = p.dbg != nullptr && tid == 0;
+    if (stampw) ts0 = wall_clock64();
     __syncthreads();          // every wave has read the previous chunk's images
+    if (stampw) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ts1 = wall_clock64(); }
     store_a(j);
     store_b(j);
+    if (stampw) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ts2 = wall_clock64(); }
     __syncthreads();
-    if (g + PF < total) {     // refill this stage: both streams, same depth (in-order vmcnt)
-      load_a(j, chunk_m0(g + PF), chunk_k0(g + PF));
-      load_b(j, chunk_k0(g + PF));
+    if (stampw) ts3 = wall_clock64();
+    if (kc + PF < nk) {       // refill this stage
+      load_a(j, KC * (kc + PF));
+      load_b(j, KC * (kc + PF));
     }
     const int ksteps = min(KC / 16, (K - KC * kc + 15) / 16);
     auto kstep = [&](const int ks) {
@@ -409,13 +511,19 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
       if (ks < ksteps) kstep(ks);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (kc == nk - 1) {       // this C tile is complete (the next tile's first chunk is already in flight)
+    if (stampw) {
+      ts4 = wall_clock64();
+      atomicAdd(p.dbg + 0, (unsigned long long)(ts1 - ts0)); atomicAdd(p.dbg + 1, (unsigned long long)(ts2 - ts1));
+      atomicAdd(p.dbg + 2, (unsigned long long)(ts3 - ts2)); atomicAdd(p.dbg + 3, (unsigned long long)(ts4 - ts3));
+      atomicAdd(p.dbg + 5, 1ull);
+    }
+    if (kc == nk - 1) {       // the C tile is complete
       epilogue(m0);
-      zero_acc();
+      if (stampw) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); atomicAdd(p.dbg + 4, (unsigned long long)(wall_clock64() - ts4)); atomicAdd(p.dbg + 6, 1ull); }
     }
   }
   if constexpr (COLSUM) {
-    if (blockIdx.y == 0) {     // thread (c4, r0) holds columns n0 + 4 c4 .. + 3 summed over its k rows: add the 8 row groups
+    if (by == 0) {     // thread (c4, r0) holds columns n0 + 4 c4 .. + 3 summed over its k rows: add the 8 row groups
       __syncthreads();
       float *red = reinterpret_cast<float *>(mm_smem);                    // [8][128]
       const int c4 = tid & 31, r0 = tid >> 5;
