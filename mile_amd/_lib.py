@@ -84,6 +84,7 @@ SIGNATURES = {
     'mile_param_count': (C.c_int64, [C.c_void_p]),
     'mile_param_offsets': (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'mile_set_data': (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'mile_set_row_window': (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64]),
     'mile_reserve': (C.c_int32, [C.c_void_p, C.c_int32]),
     'mile_set_grad_kernel': (C.c_int32, [C.c_void_p, C.c_int32]),
     'mile_get_grad_kernel': (C.c_int32, [C.c_void_p]),

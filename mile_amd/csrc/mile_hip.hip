@@ -43,6 +43,7 @@ struct mile_sampler {
   void *Xb = nullptr, *Xt = nullptr;   // bf16 copies for k_grad_w128b
   void *y = nullptr;
   int N = 0, Npad = 0, Fp = 0, Npb = 0;
+  int win_begin = 0, win_count = 0;     // mile_set_row_window: rows [begin, begin + count) only (count 0 = all)
   // workspace
   int E_cap = 0, S_cap = 0;
   float *slabs = nullptr, *llpart = nullptr, *dK = nullptr, *lold = nullptr;
@@ -367,10 +368,13 @@ int32_t mile_set_data(mile_sampler *s, const float *X, const void *y, int64_t N,
   s->Npad = ((int)N + 31) / 32 * 32;
   s->Fp = (F + 7) / 8 * 8;
   HIP_TRY(hipMalloc(&s->X, (size_t)N * F * 4));
-  HIP_TRY(hipMalloc(&s->Xp, (size_t)s->Npad * s->Fp * 4));
-  HIP_TRY(hipMalloc(&s->y, (size_t)s->Npad * 4));
+  // (32 rows of slack: a row window that ends at the last row still reads whole 32-row blocks from its own first row)
+  HIP_TRY(hipMalloc(&s->Xp, (size_t)(s->Npad + 32) * s->Fp * 4));
+  HIP_TRY(hipMalloc(&s->y, (size_t)(s->Npad + 32) * 4));
+  HIP_TRY(hipMemsetAsync(s->Xp, 0, (size_t)(s->Npad + 32) * s->Fp * 4, st));
   HIP_TRY(hipMemcpyAsync(s->X, X, (size_t)N * F * 4, hipMemcpyDeviceToDevice, st));
-  HIP_TRY(hipMemsetAsync(s->y, 0, (size_t)s->Npad * 4, st));
+  HIP_TRY(hipMemsetAsync(s->y, 0, (size_t)(s->Npad + 32) * 4, st));
+  s->win_begin = s->win_count = 0;
   HIP_TRY(hipMemcpyAsync(s->y, y, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
   const long long tot = (long long)s->Npad * s->Fp;
   k_pad_x<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(s->X, s->Xp, s->N, s->Npad, F, s->Fp);
@@ -383,6 +387,15 @@ int32_t mile_set_data(mile_sampler *s, const float *X, const void *y, int64_t N,
     k_prep_bf16<<<(unsigned)((tb + 255) / 256), 256, 0, st>>>(s->X, (bf16 *)s->Xb, (bf16 *)s->Xt, s->N, s->Npb, F);
     HIP_TRY(hipGetLastError());
   }
+  return MILE_OK;
+}
+
+int32_t mile_set_row_window(mile_sampler *s, int64_t begin, int64_t count) {
+  if (!s) return fail(MILE_ERR_INVALID, "null handle");
+  if (!s->X) return fail(MILE_ERR_STATE, "mile_set_row_window: call mile_set_data first");
+  if (begin < 0 || count < 0 || begin + count > s->N) return fail(MILE_ERR_INVALID, "mile_set_row_window: window outside the data");
+  s->win_begin = count ? (int)begin : 0;
+  s->win_count = (int)count;
   return MILE_OK;
 }
 
@@ -1009,6 +1022,17 @@ static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t s
   gp.X = s->X; gp.Xp = s->Xp; gp.y = s->y; gp.Xb = s->Xb; gp.Xt = s->Xt;
   gp.slabs = s->slabs; gp.llpart = s->llpart;
   gp.N = s->N; gp.Npad = s->Npad; gp.Npb = s->Npb; gp.Fp = s->Fp; gp.S = S; gp.R = generic_R(s->ds); gp.dp = (s->ds.d + 3) / 4 * 4;
+  if (s->win_count) {   // minibatch: the same kernels on a shifted view of the rows
+    if (kernel != MILE_GRAD_GENERIC && !is_w64(kernel))
+      return fail(MILE_ERR_STATE, "a row window needs the generic or an MFMA_W64 grad kernel");
+    if (fused_update) return fail(MILE_ERR_STATE, "row windows are for mile_logpost_grad only");
+    const int F = s->spec.in_features;
+    gp.X = s->X + (size_t)s->win_begin * F;
+    gp.Xp = s->Xp + (size_t)s->win_begin * s->Fp;
+    gp.y = (const char *)s->y + (size_t)s->win_begin * 4;
+    gp.N = s->win_count;
+    gp.Npad = (s->win_count + 31) / 32 * 32;
+  }
   { const char *dv = getenv("MILE_DEBUG"); gp.dbg = dv ? atoi(dv) : 0; }
   gp.dbg_buf = nullptr;
   if ((gp.dbg & 16) && !s->dbg_buf) HIP_TRY(hipMalloc(&s->dbg_buf, 64));

@@ -116,6 +116,11 @@ class Engine:
         self.N = int(X.shape[0])
         self._E_reserved = 0
 
+    def set_row_window(self, begin: int = 0, count: int = 0):
+        """Likelihood over rows [begin, begin + count) of the training set for the following logpost_grad calls
+        (count = 0: all rows).  The minibatches of the warm-start stage."""
+        _lib.check(self.lib.mile_set_row_window(self._h, int(begin), int(count)), self.lib)
+
     def reserve(self, E: int):
         if E > self._E_reserved:
             _lib.check(self.lib.mile_reserve(self._h, int(E)), self.lib)

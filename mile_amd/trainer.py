@@ -147,7 +147,8 @@ class BDETrainer:
                 valid_x=torch.from_numpy(vx) if len(vx) else None,
                 valid_y=torch.from_numpy(np.ascontiguousarray(self.loader.valid_y)) if len(vx) else None,
                 optimizer=ws.optimizer_config.name, optimizer_parameters=ws.optimizer_config.parameters,
-                max_epochs=ws.max_epochs, batch_size=ws.batch_size, patience=ws.patience)
+                max_epochs=ws.max_epochs, batch_size=ws.batch_size, patience=ws.patience, train_x=x, train_y=y,
+                seed=self.config.rng)
             params = theta.cpu().numpy()
             self._engine_inputs = (x, y)               # the sampler reuses the same engine (keyed by tensor identity)
             logger.info(f"\t| Warmstart Training completed after {hist['epochs']} epochs "

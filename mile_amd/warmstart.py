@@ -1,11 +1,14 @@
 """Warm-start training of the deep ensemble the chains start from (mirror of src/training/trainer.py:330-538).
 
 The reference trains every ensemble member with optax (AdamW by default) on minibatches of the mean negative
-log-likelihood, one epoch = ceil(N / batch_size) optimizer steps, validation after each epoch, per-member early
-stopping (`earlystop`, trainer.py:920-939).  Here the gradient comes from the HIP engine, which evaluates the
-FULL-batch log-posterior of all members in one launch: the loop keeps the reference's optimizer, its number of
-optimizer steps per epoch, its validation schedule and its early-stopping rule, but every step sees the whole
-training set (deterministic; documented deviation -- there is no minibatch kernel on the MI355X path).
+log-likelihood: per epoch the training rows are reshuffled and cut into len // batch_size batches of exactly
+batch_size rows (the remainder is dropped, src/dataset/tabular.py:170-212), every member sees the same batch,
+validation after each epoch, per-member early stopping (`earlystop`, trainer.py:920-939).  Here the gradient comes
+from the HIP engine: the epoch's shuffled copy of the training set is handed to it once (`set_data`) and each
+optimizer step evaluates the members on one contiguous row window of it (`mile_set_row_window`, the generic and
+width-64 MFMA kernels) -- the reference's batches, optimizer, validation schedule and early-stopping rule; only the
+permutation differs (torch's generator instead of JAX's key).  Engines whose grad kernel has no row window (wide /
+bf16 / LeNet) fall back to the same number of FULL-batch steps per epoch (round-1 behaviour, documented deviation).
 """
 from __future__ import annotations
 
@@ -69,33 +72,58 @@ class _Optimizer:
 
 def train_deep_ensemble(eng, prior, theta0: torch.Tensor, n_train: int, valid_x, valid_y, *, optimizer: str = 'adamw',
                         optimizer_parameters: dict | None = None, max_epochs: int = 100, batch_size: int | None = None,
-                        patience: int | None = None) -> tuple[torch.Tensor, dict]:
-    """Train E members in parallel on the engine's training set.  Returns (theta [E, d], history)."""
+                        patience: int | None = None, train_x=None, train_y=None, seed: int = 0) -> tuple[torch.Tensor, dict]:
+    """Train E members in parallel on the engine's training set.  Returns (theta [E, d], history).
+    ``train_x`` / ``train_y`` (the tensors the engine was built on) enable true minibatches; without them, or on a
+    grad kernel without row windows, every step sees the whole training set."""
     dev = eng.device
     theta = theta0.to(dev, torch.float32).clone()
     E = theta.shape[0]
     opt = _Optimizer(optimizer, optimizer_parameters or {}, theta)
+    minibatch = bool(batch_size) and batch_size < n_train and train_x is not None and train_y is not None and \
+        eng.grad_kernel in ('generic', 'mfma_w64', 'mfma_w64_bf16x3')
+    if minibatch:
+        n_batches = n_train // batch_size                                    # drop last, tabular.py:190-191
+        gen = torch.Generator().manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
+        tx = torch.as_tensor(train_x).reshape(n_train, -1)
+        ty = torch.as_tensor(train_y)
     steps_per_epoch = 1 if not batch_size else max(1, math.ceil(n_train / batch_size))
     has_valid = valid_x is not None and len(valid_x) > 0
     stopped = torch.zeros(E, dtype=torch.bool, device=dev)
     hist_valid = torch.empty((E, 0), device=dev)
     train_nll = None
     epoch = -1
-    for epoch in range(max_epochs):
-        if bool(stopped.all()):
-            break
-        for _ in range(steps_per_epoch):
-            logp, g = eng.logpost_grad(theta)
-            lp_prior, g_prior = prior_value_and_grad(prior, theta)
-            grad_nll = -(g - g_prior) / n_train                         # gradient of the mean negative log-likelihood
-            train_nll = -(logp - lp_prior) / n_train
-            theta = opt.step(theta, grad_nll, ~stopped)
-        if has_valid:
-            v = -eng.pointwise_loglik(theta, valid_x, valid_y).mean(dim=-1)          # [E]
-            hist_valid = torch.cat([hist_valid, v[:, None]], dim=1)
-            if patience:
-                stopped = stopped | earlystop(hist_valid, patience)
-            logger.info(f'Epoch {epoch} | Validation Loss: {v.mean().item():.4f} | early stopped: {int(stopped.sum())}/{E}')
+    try:
+        for epoch in range(max_epochs):
+            if bool(stopped.all()):
+                break
+            if minibatch:
+                perm = torch.randperm(n_train, generator=gen)                # loader.shuffle() between epochs
+                eng.set_data(tx[perm], ty[perm])
+                for b in range(n_batches):
+                    eng.set_row_window(b * batch_size, batch_size)
+                    logp, g = eng.logpost_grad(theta)
+                    lp_prior, g_prior = prior_value_and_grad(prior, theta)
+                    grad_nll = -(g - g_prior) / batch_size                   # gradient of the batch-mean negative log-likelihood
+                    train_nll = -(logp - lp_prior) / batch_size
+                    theta = opt.step(theta, grad_nll, ~stopped)
+                eng.set_row_window(0, 0)
+            else:
+                for _ in range(steps_per_epoch):
+                    logp, g = eng.logpost_grad(theta)
+                    lp_prior, g_prior = prior_value_and_grad(prior, theta)
+                    grad_nll = -(g - g_prior) / n_train                      # gradient of the mean negative log-likelihood
+                    train_nll = -(logp - lp_prior) / n_train
+                    theta = opt.step(theta, grad_nll, ~stopped)
+            if has_valid:
+                v = -eng.pointwise_loglik(theta, valid_x, valid_y).mean(dim=-1)          # [E]
+                hist_valid = torch.cat([hist_valid, v[:, None]], dim=1)
+                if patience:
+                    stopped = stopped | earlystop(hist_valid, patience)
+                logger.info(f'Epoch {epoch} | Validation Loss: {v.mean().item():.4f} | early stopped: {int(stopped.sum())}/{E}')
+    finally:
+        if minibatch:                                                        # the sampler wants the full set, original order
+            eng.set_data(tx, ty)
     hist = {'epochs': epoch + 1, 'valid_nll': hist_valid.cpu(), 'train_nll': None if train_nll is None else train_nll.cpu(),
-            'stopped': stopped.cpu()}
+            'stopped': stopped.cpu(), 'minibatch': minibatch}
     return theta, hist

@@ -304,3 +304,28 @@ def test_layerwise_path_agrees_with_generic_kernel_on_random_shapes(oracle):
         b = _engine(oracle, ospec, prob, 'gemm_f32').logpost_grad(th)
         assert _relerr(b[0].cpu().numpy(), a[0].cpu().numpy()) < 2e-5, (trial, F, hs, act, task)
         assert _relerr(b[1].cpu().numpy(), a[1].cpu().numpy()) < 5e-5, (trial, F, hs, act, task)
+
+
+@pytest.mark.parametrize('kernel', ['generic', 'mfma_w64', 'mfma_w64_bf16x3'])
+def test_row_window_is_the_minibatch_gradient(oracle, kernel):
+    """mile_set_row_window (the minibatches of the warm-start stage, src/dataset/tabular.py:170-212 +
+    src/training/trainer.py:706-760): the gradient over rows [begin, begin + count) equals the oracle's on those rows --
+    windows at the start, in the middle (not 32-aligned), and ending at the last row; count = 0 restores the full set."""
+    ospec = oracle.ModelSpec(5, (64, 64, 64, 2))
+    N, E = 301, 5
+    prob = oracle.synthetic_problem(ospec, N, E, seed=17)
+    eng = _engine(oracle, ospec, prob, kernel)
+    th = torch.from_numpy(prob['theta0'])
+    full = eng.logpost_grad(th)
+    for begin, count in ((0, 32), (45, 32), (64, 100), (N - 32, 32), (N - 7, 7)):
+        eng.set_row_window(begin, count)
+        lp, g = eng.logpost_grad(th)
+        lp_ref, g_ref = oracle.logpost_and_grad(ospec, prob['theta0'].astype(np.float64), prob['X'][begin:begin + count],
+                                                prob['y'][begin:begin + count])
+        assert _relerr(lp.cpu().numpy(), lp_ref) < 2e-5, (kernel, begin, count)
+        assert _relerr(g.cpu().numpy(), g_ref) < 2e-5, (kernel, begin, count)
+    eng.set_row_window(0, 0)
+    lp, g = eng.logpost_grad(th)
+    assert torch.equal(lp, full[0]) and torch.equal(g, full[1])
+    with pytest.raises(Exception, match='window'):
+        eng.set_row_window(N - 3, 7)
