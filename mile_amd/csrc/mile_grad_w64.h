@@ -110,14 +110,33 @@ __device__ __forceinline__ float trunc_bf16(float x) { return __uint_as_float(__
 
 // One 32x32 T-layout tile (lane = data row j, reg r = feature tfeat(r,h)) -> packed bf16 pairs of its three terms:
 // pk[t][q] = {term t of reg 2q+1 : term t of reg 2q}.
+// MILE_SPLIT_DOT2 (default): the residual x - top(x) straight from the PACKED term with one v_dot2c_f32_bf16 per element
+// (x + pk.lo * -1 + pk.hi * 0; every partial sum is exact) instead of v_and + half a v_pk_add: 7 VALU per pair, not 9.
+#ifndef MILE_SPLIT_DOT2
+#define MILE_SPLIT_DOT2 1
+#endif
+__device__ __forceinline__ float sub_lo(uint32_t pk, float x) {   // x - (low bf16 of pk)
+  const bf16x2 m = {(bf16)-1.0f, (bf16)0.0f};
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pk), m, x, false);
+}
+__device__ __forceinline__ float sub_hi(uint32_t pk, float x) {   // x - (high bf16 of pk)
+  const bf16x2 m = {(bf16)0.0f, (bf16)-1.0f};
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pk), m, x, false);
+}
 __device__ __forceinline__ void split3_pk(const f32x16 &T, uint32_t (&pk)[3][8]) {
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const f32x2 x = {T[2 * q], T[2 * q + 1]};
     pk[0][q] = hi16_pair(x[1], x[0]);
+#if MILE_SPLIT_DOT2
+    const f32x2 r = {sub_lo(pk[0][q], x[0]), sub_hi(pk[0][q], x[1])};
+    pk[1][q] = hi16_pair(r[1], r[0]);
+    const f32x2 s = {sub_lo(pk[1][q], r[0]), sub_hi(pk[1][q], r[1])};
+#else
     const f32x2 r = x - f32x2{trunc_bf16(x[0]), trunc_bf16(x[1])};
     pk[1][q] = hi16_pair(r[1], r[0]);
     const f32x2 s = r - f32x2{trunc_bf16(r[0]), trunc_bf16(r[1])};
+#endif
     pk[2][q] = hi16_pair(s[1], s[0]);
   }
 }

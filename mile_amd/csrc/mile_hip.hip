@@ -474,9 +474,56 @@ static void launch_update_al(const UpdParams &u, int E, int nk, hipStream_t st) 
 #undef MILE_UPD_CASE
 }
 
+// d beyond the register cache, up to 4 * UPD_NT * UPD_QMAX_BIG: k_update_big (x, u in registers, g in LDS)
+template <int AL, bool SDC>
+static bool launch_update_big_al(const UpdParams &u, int E, int nk, hipStream_t st) {
+  const int nqf = u.d >> 2;
+  const int nt = std::min(UPD_NT, ((nqf + nk - 1) / nk + 63) / 64 * 64);
+  const size_t lds = (size_t)nk * nt * 16;
+  // no compile-time launch kinds here: with the flag tests folded the unrolled quads become one basic block, the compiler
+  // interleaves them and spills 109 registers (NK = 9, record kind) against 7 with the run-time flags
+#define MILE_UPD_BIG(NK_, CF_)                                                                                     \
+  {                                                                                                                \
+    static bool attr = false;                                                                                      \
+    if (!attr) {                                                                                                   \
+      if (hipFuncSetAttribute((const void *)k_update_big<NK_, AL, SDC, CF_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              UPD_NT * NK_ * 16) != hipSuccess) return false;                                      \
+      attr = true;                                                                                                 \
+    }                                                                                                              \
+    k_update_big<NK_, AL, SDC, CF_><<<E, nt, lds, st>>>(u);                                                        \
+    return true;                                                                                                   \
+  }
+#define MILE_UPD_BIG_CASE(NK_) \
+  case NK_:                    \
+    MILE_UPD_BIG(NK_, -1)
+  switch (nk) {
+    MILE_UPD_BIG_CASE(5)
+    MILE_UPD_BIG_CASE(6)
+    MILE_UPD_BIG_CASE(7)
+    MILE_UPD_BIG_CASE(8)
+    MILE_UPD_BIG_CASE(9)
+  }
+#undef MILE_UPD_BIG_CASE
+#undef MILE_UPD_BIG
+  return false;
+}
+
+static bool launch_update_big(const UpdParams &u, int E, hipStream_t st) {
+  const int nqf = u.d >> 2;
+  const int nk = (nqf + UPD_NT - 1) / UPD_NT;
+  if (nk <= UPD_QMAX || nk > UPD_QMAX_BIG || (u.flags & UPD_TUNE) || u.zA || u.zB || getenv("MILE_NO_UPD_BIG")) return false;
+  int al = (u.d % 4 == 0) ? 4 : ((u.d % 2 == 0) ? 2 : 1);
+  const void *ptrs[] = {u.x, u.u, u.g, u.slabs, u.sdc, u.zA, u.zB, u.out_sample, u.x_in, u.u_in, u.g_in};
+  for (const void *q : ptrs)
+    if (q) al = std::min(al, ptr_align(q));
+  if (u.sdc) return al == 4 ? launch_update_big_al<4, true>(u, E, nk, st) : (al == 2 ? launch_update_big_al<2, true>(u, E, nk, st) : launch_update_big_al<1, true>(u, E, nk, st));
+  return al == 4 ? launch_update_big_al<4, false>(u, E, nk, st) : (al == 2 ? launch_update_big_al<2, false>(u, E, nk, st) : launch_update_big_al<1, false>(u, E, nk, st));
+}
+
 static void launch_update(const UpdParams &u, int E, hipStream_t st) {
   const int nqf = u.d >> 2;
   if (nqf < 1 || nqf > UPD_NT * UPD_QMAX) {
+    if (nqf >= 1 && launch_update_big(u, E, st)) return;
     if ((u.d + 3) / 4 <= UPD_NT * UPD_QMAX) k_update<true><<<E, UPD_NT, 0, st>>>(u);
     else k_update<false><<<E, UPD_NT, 0, st>>>(u);
     return;

@@ -57,6 +57,17 @@ __device__ __forceinline__ uint32_t mm_hi16_pair(float x1, float x0) {   // {bf1
   return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
 }
 __device__ __forceinline__ float mm_trunc(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+#ifndef MILE_SPLIT_DOT2
+#define MILE_SPLIT_DOT2 1
+#endif
+__device__ __forceinline__ float mm_sub_lo(uint32_t pk, float x) {   // x - (low bf16 of pk), exact
+  const bf16x2 m = {(bf16)-1.0f, (bf16)0.0f};
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pk), m, x, false);
+}
+__device__ __forceinline__ float mm_sub_hi(uint32_t pk, float x) {   // x - (high bf16 of pk), exact
+  const bf16x2 m = {(bf16)0.0f, (bf16)-1.0f};
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pk), m, x, false);
+}
 
 // four fp32 values -> TERMS packed bf16 quadruples (8 bytes each)
 template <int TERMS>
@@ -67,9 +78,15 @@ __device__ __forceinline__ void mm_split4(const f32x4 x, mm_u32x2 (&pk)[TERMS]) 
   } else {
     static_assert(TERMS == 3, "one or three terms");
     pk[0] = mm_u32x2{mm_hi16_pair(x[1], x[0]), mm_hi16_pair(x[3], x[2])};
+#if MILE_SPLIT_DOT2   // residuals from the packed term, one v_dot2c_f32_bf16 per element (mile_grad_w64.h, split3_pk)
+    const f32x4 r = {mm_sub_lo(pk[0][0], x[0]), mm_sub_hi(pk[0][0], x[1]), mm_sub_lo(pk[0][1], x[2]), mm_sub_hi(pk[0][1], x[3])};
+    pk[1] = mm_u32x2{mm_hi16_pair(r[1], r[0]), mm_hi16_pair(r[3], r[2])};
+    const f32x4 q = {mm_sub_lo(pk[1][0], r[0]), mm_sub_hi(pk[1][0], r[1]), mm_sub_lo(pk[1][1], r[2]), mm_sub_hi(pk[1][1], r[3])};
+#else
     const f32x4 r = {x[0] - mm_trunc(x[0]), x[1] - mm_trunc(x[1]), x[2] - mm_trunc(x[2]), x[3] - mm_trunc(x[3])};
     pk[1] = mm_u32x2{mm_hi16_pair(r[1], r[0]), mm_hi16_pair(r[3], r[2])};
     const f32x4 q = {r[0] - mm_trunc(r[0]), r[1] - mm_trunc(r[1]), r[2] - mm_trunc(r[2]), r[3] - mm_trunc(r[3])};
+#endif
     pk[2] = mm_u32x2{mm_hi16_pair(q[1], q[0]), mm_hi16_pair(q[3], q[2])};
   }
 }

@@ -350,9 +350,13 @@ __device__ __forceinline__ float ld1_shared(const float *q) {
 // prior, step-O refresh).
 #define UPD_KIND_MID (UPD_FROM_SLABS | UPD_B1 | UPD_A | UPD_NO_G)
 #define UPD_KIND_REC (UPD_FROM_SLABS | UPD_B1 | UPD_OA | UPD_RECORD | UPD_OB | UPD_B2 | UPD_A | UPD_NO_G)
-template <int NK, int AL, bool SDC, bool COH, int CF = -1>
+// BIG (d beyond UPD_QMAX quads per thread, up to UPD_QMAX_BIG): only u stays in registers, x is read twice, the gradient waits in the
+// workgroup's LDS array `gl` ([NK][nt] quads, <= 147 KB) and the O-step noise is generated twice (pass 1 for the sums, pass 2
+// for the update) -- five register-resident arrays of 9 quads do not fit the 128 registers a 1024-thread workgroup has.
+template <int NK, int AL, bool SDC, bool COH, int CF = -1, bool BIG = false>
 __device__ __forceinline__ void upd_fast_body(const UpdParams &p, const int e, const int tid, const int nt,
-                                              float (*red)[UPD_NSUM + 1], float *bc, long long *stamps = nullptr) {
+                                              float (*red)[UPD_NSUM + 1], float *bc, long long *stamps = nullptr,
+                                              f32x4 *gl = nullptr) {
   const int d = p.d;
   const int flags = CF >= 0 ? CF : p.flags;
   const size_t base = (size_t)e * d;
@@ -379,26 +383,31 @@ __device__ __forceinline__ void upd_fast_body(const UpdParams &p, const int e, c
   if (from_slabs)
     for (int s = 0; s < p.S; ++s) ll_in += ld1_shared<COH>(p.llpart + (size_t)e * p.S + s);
 
-  f32x4 cx[NK], cu[NK], cg[NK], ca[NK], cb[NK], csd[SDC ? NK : 1];
+  constexpr int NR = BIG ? 1 : NK;   // quads of g / noise a thread keeps in registers
+  f32x4 cx[BIG ? 1 : NK], cu[NK], cg[NR], ca[NR], cb[NR], csd[SDC ? NK : 1];
   // ---- pass 1: loads -----------------------------------------------------------------
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
     const int q = tid + k * nt;
     const bool valid = q < nqf;
     const size_t o = base + 4 * (size_t)(valid ? q : 0);
-    cx[k] = ld4<AL>(xin + o);
+    if constexpr (!BIG) cx[k] = ld4<AL>(xin + o);
     cu[k] = ld4<AL>(uin + o);
+    f32x4 g;
     if (from_slabs) {
       const int so = (int)(o - base);
-      f32x4 g = ld4_slab<AL, COH>(sl, sl_rs, so);
+      g = ld4_slab<AL, COH>(sl, sl_rs, so);
       for (int s = 1; s < p.S; ++s) g += ld4_slab<AL, COH>(sl, sl_rs, s * p.dp + so);
-      cg[k] = g;
     } else {
-      cg[k] = ld4<AL>(gin + o);
+      g = ld4<AL>(gin + o);
     }
+    if constexpr (BIG) gl[k * nt + tid] = g;
+    else cg[k] = g;
     if constexpr (SDC) csd[k] = ld4<AL>(p.sdc + o);
-    ca[k] = explA ? ld4<AL>(p.zA + o) : f32x4{0, 0, 0, 0};
-    cb[k] = explB ? ld4<AL>(p.zB + o) : f32x4{0, 0, 0, 0};
+    if constexpr (!BIG) {
+      ca[k] = explA ? ld4<AL>(p.zA + o) : f32x4{0, 0, 0, 0};
+      cb[k] = explB ? ld4<AL>(p.zB + o) : f32x4{0, 0, 0, 0};
+    }
   }
   // tail element (at most 3 per particle): thread t < ntail owns element 4*nqf + t
   const bool has_tail = tid < ntail;
@@ -419,8 +428,16 @@ __device__ __forceinline__ void upd_fast_body(const UpdParams &p, const int e, c
 #pragma unroll
   for (int k = 0; k < UPD_NSUM; ++k) sm[k] = 0.0f;
 #pragma unroll
-  for (int k = 0; k < NK; ++k) {
-    const int q = tid + k * nt;
+  for (int kq = 0; kq < NK; ++kq) {
+    const int q = tid + kq * nt;
+    const int k = BIG ? 0 : kq;          // register slot of g / noise
+    if constexpr (BIG) {
+      // x is read again in pass 2 instead of held (MALL-resident; spills cost more).  No explicit-noise hooks in this form.
+      cx[0] = ld4<AL>(xin + base + (unsigned)(4 * (q < nqf ? q : 0)));
+      cg[0] = gl[kq * nt + tid];
+      ca[0] = f32x4{0, 0, 0, 0};
+      cb[0] = f32x4{0, 0, 0, 0};
+    }
     if (useA && !p.zA) ca[k] = philox_normal4(q, pid, p.stepA, p.stageA, p.seed);
     if (useB && !p.zB) cb[k] = philox_normal4(q, pid, p.stepB, p.stageB, p.seed);
     const float mk = q < nqf ? 1.0f : 0.0f;
@@ -435,8 +452,8 @@ __device__ __forceinline__ void upd_fast_body(const UpdParams &p, const int e, c
       }
       cg[k][m] = gi;                       // un-preconditioned gradient (stored below)
       if (tune) sm[11] += (mk != 0.0f && !isfinite(xi)) ? 1.0f : 0.0f;
-      const float gs = (SDC ? gi * csd[k][m] : gi) * mk;
-      const float ui = cu[k][m] * mk, a = ca[k][m] * mk, b = cb[k][m] * mk;
+      const float gs = (SDC ? gi * csd[kq][m] : gi) * mk;
+      const float ui = cu[kq][m] * mk, a = ca[k][m] * mk, b = cb[k][m] * mk;
       ca[k][m] = a; cb[k][m] = b;
       sm[0] = fmaf(ui, ui, sm[0]); sm[1] = fmaf(ui, gs, sm[1]); sm[2] = fmaf(gs, gs, sm[2]);
       sm[3] = fmaf(ui, a, sm[3]); sm[4] = fmaf(gs, a, sm[4]); sm[5] = fmaf(a, a, sm[5]);
@@ -446,7 +463,11 @@ __device__ __forceinline__ void upd_fast_body(const UpdParams &p, const int e, c
     if (store_g && q < nqf) st4<AL>(p.g + base + 4 * (size_t)q, cg[k]);
     if constexpr (SDC) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) cg[k][m] *= csd[k][m];   // keep g~ = g*s for pass 2
+      for (int m = 0; m < 4; ++m) cg[k][m] *= csd[kq][m];   // keep g~ = g*s for pass 2
+    }
+    if constexpr (BIG) {
+      gl[kq * nt + tid] = cg[0];
+      __builtin_amdgcn_sched_barrier(0);   // one quad at a time: interleaved iterations spill (128 registers per thread)
     }
   }
   if (stamps) stamps[3] = wall_clock64();
@@ -591,10 +612,25 @@ __device__ __forceinline__ void upd_fast_body(const UpdParams &p, const int e, c
   const bool t_acc = tune && p.t_mask == 0.0f;              // streaming_average_update of [x, x^2]
   const float t_den = 1.0f / (t_Wold + t_wgt);              // zero_prevention = mask = 0 here
 #pragma unroll
-  for (int k = 0; k < NK; ++k) {
-    const int q = tid + k * nt;
+  for (int kq = 0; kq < NK; ++kq) {
+    const int q = tid + kq * nt;
+    const int k = BIG ? 0 : kq;
     if (q < nqf) {
       const size_t o = base + 4 * (size_t)q;
+      if constexpr (BIG) {
+        cx[0] = ld4<AL>(xin + base + (unsigned)(4 * q));
+        cg[0] = gl[kq * nt + tid];
+        if (flags & (UPD_OA | UPD_OB)) {   // the noise of pass 1 again (same counters)
+          ca[0] = f32x4{0, 0, 0, 0};
+          cb[0] = f32x4{0, 0, 0, 0};
+          int q2 = q;
+          asm volatile("" : "+v"(q2));     // opaque: otherwise the compiler keeps pass 1's values alive instead (111 spills)
+          if (useA && !p.zA) ca[0] = philox_normal4(q2, pid, p.stepA, p.stageA, p.seed);
+          if (useB && !p.zB) cb[0] = philox_normal4(q2, pid, p.stepB, p.stageB, p.seed);
+        } else {
+          ca[0] = f32x4{0, 0, 0, 0}; cb[0] = f32x4{0, 0, 0, 0};
+        }
+      }
       if (t_acc) {
         float *a0 = p.t_avg + (size_t)e * 2 * d + 4 * (size_t)q, *a1 = a0 + d;
         f32x4 m0 = ld4<AL>(a0), m1 = ld4<AL>(a1);
@@ -606,20 +642,21 @@ __device__ __forceinline__ void upd_fast_body(const UpdParams &p, const int e, c
         st4<AL>(a0, m0);
         st4<AL>(a1, m1);
       }
-      f32x4 v = cu[k];
+      f32x4 v = cu[kq];
       if (any_op) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) v[m] = fmaf(c0, cu[k][m], fmaf(c1, cg[k][m], fmaf(c2, ca[k][m], c3 * cb[k][m])));
+        for (int m = 0; m < 4; ++m) v[m] = fmaf(c0, cu[kq][m], fmaf(c1, cg[k][m], fmaf(c2, ca[k][m], c3 * cb[k][m])));
         st4<AL>(p.u + o, v);
       }
       if (p.out_sample) st4<AL>(p.out_sample + o, cx[k]);
       if (doA) {
         f32x4 xn;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) xn[m] = fmaf(SDC ? ea * csd[k][m] : ea, v[m], cx[k][m]);
+        for (int m = 0; m < 4; ++m) xn[m] = fmaf(SDC ? ea * csd[kq][m] : ea, v[m], cx[k][m]);
         st4<AL>(p.x + o, xn);
       }
     }
+    if constexpr (BIG) __builtin_amdgcn_sched_barrier(0);
   }
   if (has_tail) {
     if (t_acc) {
@@ -641,6 +678,17 @@ static __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p
   // launched with the fewest waves that still give NK quads per thread (nt = blockDim.x <= UPD_NT, a multiple of 64): the
   // kernel is VALU-bound on half the chip (E workgroups), so idle padded lanes cost real time (d = 8834: 768 threads, not 1024)
   upd_fast_body<NK, AL, SDC, false, CF>(p, blockIdx.x, threadIdx.x, blockDim.x, red, bc);
+}
+
+// d beyond the register cache (B3: d = 34 562): NK = 5 .. UPD_QMAX_BIG quads per thread, g parked in dynamic LDS
+// (NK * blockDim.x quads).  No tuner in this form (mile_tune runs k_tune_post after the step for these sizes).
+#define UPD_QMAX_BIG 9
+template <int NK, int AL, bool SDC, int CF = -1>
+static __global__ __launch_bounds__(UPD_NT) void k_update_big(const UpdParams p) {
+  __shared__ float red[UPD_NW][UPD_NSUM + 1];
+  __shared__ float bc[8];
+  extern __shared__ __attribute__((aligned(16))) char upd_gl[];
+  upd_fast_body<NK, AL, SDC, false, CF, true>(p, blockIdx.x, threadIdx.x, blockDim.x, red, bc, nullptr, reinterpret_cast<f32x4 *>(upd_gl));
 }
 
 // which compile-time kind a launch is (else -1): steady-state flag words with a Normal prior, no tuner, no preconditioner

@@ -114,6 +114,38 @@ def test_preconditioned_steps_and_alignment_paths(oracle, F, hs):
     assert np.abs(s.momentum.cpu().numpy() - st.momentum).max() < 1e-4
 
 
+@pytest.mark.parametrize('F,hs,sdc', [(9, (128, 128, 2), False), (7, (129, 127, 2), True), (16, (128, 128, 128, 2), False)])
+def test_update_kernel_beyond_the_register_cache_matches_the_two_pass_form(oracle, monkeypatch, F, hs, sdc):
+    """16384 < d <= 36864 (B3: 34562): `k_update_big` -- u in registers, g parked in LDS, noise generated twice -- against
+    the two-pass `k_update` (MILE_NO_UPD_BIG) on the same Philox streams: same trajectory up to fp32 summation order, same
+    kept samples, unit momentum.  Cases: NK = 5 (16-byte rows), d % 4 == 2 with a preconditioner, NK = 9 (B3's d)."""
+    ospec = oracle.ModelSpec(F, hs)
+    d = ospec.n_params
+    assert 16384 < d <= 36864
+    E, T = 5, 6
+    prob = oracle.synthetic_problem(ospec, 96, E, seed=21)
+    rng = np.random.default_rng(2)
+    kw = dict(n_steps=T, seed=11, n_thinning=2, particle_ids=torch.arange(E, dtype=torch.int32))
+    if sdc:
+        kw['sqrt_diag_cov'] = torch.from_numpy((0.5 + rng.random((E, d))).astype(np.float32))
+    eps, L = torch.from_numpy(prob['eps']), torch.from_numpy(prob['L'])
+    out = {}
+    for two_pass in (False, True):
+        if two_pass:
+            monkeypatch.setenv('MILE_NO_UPD_BIG', '1')
+        eng = _engine(ospec, prob['X'], prob['y'], 'generic')
+        s0 = eng.init(torch.from_numpy(prob['theta0']), seed=11, particle_ids=kw['particle_ids'])
+        out[two_pass] = eng.step(s0, eps, L, **kw)
+    (sa, ia, ka), (sb, ib, kb) = out[False], out[True]
+    assert _rel(sa.position.cpu(), sb.position.cpu()) < 2e-5
+    assert np.abs(sa.momentum.cpu().numpy() - sb.momentum.cpu().numpy()).max() < 2e-5
+    assert _rel(ka.cpu(), kb.cpu()) < 2e-5
+    assert _rel(sa.logdensity.cpu(), sb.logdensity.cpu()) < 1e-5
+    ulp = float(np.spacing(np.float32(sb.logdensity.abs().max().item())))   # energy_change carries a difference of log-densities
+    assert np.abs(ia.energy_change.cpu().numpy() - ib.energy_change.cpu().numpy()).max() <= 4 * ulp + 1e-5
+    assert (sa.momentum.double().norm(dim=1) - 1).abs().max().item() < 1e-5 or sdc
+
+
 def test_kernel_registry_factory_has_blackjax_shape(oracle):
     from mile_amd.kernels import KERNELS
     from mile_amd.probabilistic import ProbabilisticModel
