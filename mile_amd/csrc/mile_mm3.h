@@ -58,7 +58,7 @@ __device__ __forceinline__ uint32_t mm_hi16_pair(float x1, float x0) {   // {bf1
 }
 __device__ __forceinline__ float mm_trunc(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
 #ifndef MILE_SPLIT_DOT2
-#define MILE_SPLIT_DOT2 1
+#define MILE_SPLIT_DOT2 0
 #endif
 __device__ __forceinline__ float mm_sub_lo(uint32_t pk, float x) {   // x - (low bf16 of pk), exact
   const bf16x2 m = {(bf16)-1.0f, (bf16)0.0f};
