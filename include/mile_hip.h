@@ -72,7 +72,10 @@ typedef enum mile_grad_kernel {
   MILE_GRAD_MFMA_WIDE_BF16X3 = 7, /* any FCN, layer-wise: hand-written batched MFMA GEMMs (k_mm3) with the same fp32-faithful
                                      three-term bf16 products, bias / activation / activation-derivative fused into their
                                      epilogues; what AUTO picks for wide nets (hidden width >= 96: B4's 4 x 256 softmax net) */
-  MILE_GRAD_MFMA_WIDE_BF16 = 8    /* the same kernels with bf16-ROUNDED operands (one product instead of six); explicit only */
+  MILE_GRAD_MFMA_WIDE_BF16 = 8,   /* the same kernels with bf16-ROUNDED operands (one product instead of six); explicit only */
+  MILE_GRAD_LENET_BF16 = 9        /* MILE_MODEL_LENET, <= 4 image channels: the five convolution products as implicit GEMMs on
+                                     v_mfma_f32_16x16x32_bf16 with bf16-ROUNDED operands (BASELINE config 5 names bf16), the rest
+                                     as LENET_F32; explicit only */
 } mile_grad_kernel;
 /* Which network: the FCN (src/models/tabular/fcn.py:16-28) or LeNet (src/models/images/cnns.py:10-66). */
 typedef enum mile_model { MILE_MODEL_FCN = 0, MILE_MODEL_LENET = 1 } mile_model;

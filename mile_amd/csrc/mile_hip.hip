@@ -19,6 +19,7 @@
 #include "mile_grad_gemm.h"
 #include "mile_mm3.h"
 #include "mile_lenet.h"
+#include "mile_lenet_mfma.h"
 #include "mile_predict.h"
 #include "mile_update.h"
 
@@ -139,7 +140,7 @@ static bool w128b_supported(const mile_model_spec &sp) {
 }
 
 static int resolved_kernel(const mile_sampler *s) {
-  if (s->spec.model == MILE_MODEL_LENET) return MILE_GRAD_LENET_F32;
+  if (s->spec.model == MILE_MODEL_LENET) return s->grad_kernel == MILE_GRAD_LENET_BF16 ? MILE_GRAD_LENET_BF16 : MILE_GRAD_LENET_F32;
   if (s->grad_kernel == MILE_GRAD_AUTO) {
     if (w64x3_supported(s->spec)) return MILE_GRAD_MFMA_W64_BF16X3;   // fp32-faithful and never slower than MFMA_W64
     if (w64_supported(s->spec)) return MILE_GRAD_MFMA_W64;
@@ -164,7 +165,7 @@ static int choose_S(const mile_sampler *s, int E, int kernel) {
     S = std::min(S, std::max(1, NB / 4));  // keep >= 4 row blocks (one per wave) per workgroup
     return S;
   }
-  if (kernel == MILE_GRAD_GEMM_F32 || kernel == MILE_GRAD_LENET_F32 || kernel == MILE_GRAD_MFMA_WIDE_BF16X3 ||
+  if (kernel == MILE_GRAD_GEMM_F32 || kernel == MILE_GRAD_LENET_F32 || kernel == MILE_GRAD_LENET_BF16 || kernel == MILE_GRAD_MFMA_WIDE_BF16X3 ||
       kernel == MILE_GRAD_MFMA_WIDE_BF16)
     return 1;
   if (kernel == MILE_GRAD_MFMA_W128_BF16) {
@@ -425,11 +426,12 @@ int32_t mile_reserve(mile_sampler *s, int32_t E) {
 
 int32_t mile_set_grad_kernel(mile_sampler *s, int32_t which) {
   if (!s) return fail(MILE_ERR_INVALID, "null handle");
-  if (which < MILE_GRAD_AUTO || which > MILE_GRAD_MFMA_WIDE_BF16) return fail(MILE_ERR_INVALID, "unknown grad kernel");
+  if (which < MILE_GRAD_AUTO || which > MILE_GRAD_LENET_BF16) return fail(MILE_ERR_INVALID, "unknown grad kernel");
   if ((which == MILE_GRAD_MFMA_WIDE_BF16X3 || which == MILE_GRAD_MFMA_WIDE_BF16) && s->spec.model != MILE_MODEL_FCN)
     return fail(MILE_ERR_INVALID, "MFMA_WIDE_* are FCN kernels");
-  if ((s->spec.model == MILE_MODEL_LENET) != (which == MILE_GRAD_LENET_F32) && which != MILE_GRAD_AUTO)
-    return fail(MILE_ERR_INVALID, "LENET_F32 is the (only) kernel of MILE_MODEL_LENET");
+  if ((s->spec.model == MILE_MODEL_LENET) != (which == MILE_GRAD_LENET_F32 || which == MILE_GRAD_LENET_BF16) && which != MILE_GRAD_AUTO)
+    return fail(MILE_ERR_INVALID, "LENET_F32 / LENET_BF16 are the kernels of MILE_MODEL_LENET, and its only ones");
+  if (which == MILE_GRAD_LENET_BF16 && s->lg.C > 4) return fail(MILE_ERR_INVALID, "LENET_BF16 needs <= 4 image channels");
   if (which == MILE_GRAD_GEMM_F32 && !rocblas_load()) return fail(MILE_ERR_HIP, "GEMM_F32 needs librocblas.so, which could not be loaded");
   if (which == MILE_GRAD_MFMA_W128_BF16 && !w128b_supported(s->spec))
     return fail(MILE_ERR_INVALID, "MFMA_W128_BF16 needs ReLU regression with 1-3 hidden layers of width 128 and F <= 16");
@@ -621,7 +623,7 @@ __global__ void k_fill(float *p, float v, int n) {
 // out_ll != nullptr: evaluation, per-row log-likelihoods out_ll[(s0 + e) * N + r]; otherwise the gradient goes
 // to slab[e * dp + offset] and the log-likelihood sums to llacc[e].
 static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X, const void *y, int N, float *slab, long long dp,
-                     float *llacc, float *out_ll, long long s0, hipStream_t st) {
+                     float *llacc, float *out_ll, long long s0, hipStream_t st, bool mfma = false) {
   if (!rocblas_load()) return fail(MILE_ERR_HIP, "librocblas.so could not be loaded");
   const LeNetGeom &g = s->lg;
   const int d = g.d, act = s->ds.activation, task = s->ds.task;
@@ -643,6 +645,11 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
   // compile-time geometry for CIFAR- / MNIST-sized inputs (their LDS needs are below the 64 KiB default limit)
   const int geo = (g.C == 3 && g.H == 32 && g.W == 32) ? 1 : (g.C == 1 && g.H == 28 && g.W == 28) ? 3 : 0;
   const bool direct = getenv("MILE_LENET_GEMM") == nullptr && g.C <= 16 && lds_max <= 150 * 1024;
+  // MILE_GRAD_LENET_BF16: the five convolution launches on the bf16 matrix pipe (mile_lenet_mfma.h), everything else as below
+  const size_t ldm_f1 = cm_lds_fwd(CM_IN4, g.H, g.W, 2), ldm_f2 = cm_lds_fwd(CM_IN8, g.hp1, g.wp1, 0), ldm_x2 = cm_lds_dx(g.h2, g.w2);
+  const size_t ldm_w1 = cm_lds_dw(CM_IN4, g.H, g.W, 2), ldm_w2 = cm_lds_dw(CM_IN8, g.hp1, g.wp1, 0);
+  if (mfma && (!direct || g.C > 4 || std::max({ldm_f1, ldm_f2, ldm_x2, ldm_w1, ldm_w2}) > 150 * 1024))
+    return fail(MILE_ERR_INVALID, "LENET_BF16 needs <= 4 image channels and an image that fits the LDS tiles");
   size_t per = n_a1 + n_p1 + (direct ? 0 : n_col2) + n_a2 + n_p2 + 120 + 84 + g.K;
   if (grad) per += 84 + 120 + n_p2 + n_p1 + (direct ? 0 : n_a2 + n_a1);
   const size_t shared = direct ? 0 : 25 * (size_t)g.C * HW;
@@ -684,6 +691,11 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
       HIP_TRY(hipFuncSetAttribute((const void *)k_conv5_dw<6, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void *)k_conv5_dw<16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
       HIP_TRY(hipFuncSetAttribute((const void *)k_conv5_dx<6, 16, 1, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void *)k_conv5m_fwd<CM_IN4, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void *)k_conv5m_fwd<CM_IN8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void *)k_conv5m_dw<CM_IN4, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void *)k_conv5m_dw<CM_IN8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void *)k_conv5m_dx<6, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
       attr_done = true;
     }
   }
@@ -706,9 +718,11 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
     if (direct) {
 #define LAUNCH_FWD1(GEO_) k_conv5_fwd<6, GEO_><<<dim3(nwg, E), 256, lds_f1, st>>>(Xc, 0, (long long)g.C * HW, g.W, 1, (long long)HW, g.C, g.H, g.W, 2, theta, g.k_c1, g.b_c1, d, a1, (int)Rc, ipw, act)
 #define LAUNCH_FWD2(GEO_) k_conv5_fwd<16, GEO_><<<dim3(nwg, E), 256, lds_f2, st>>>(p1, Rc * (long long)n_p1, (long long)n_p1, g.wp1 * 6, 6, 1, 6, g.hp1, g.wp1, 0, theta, g.k_c2, g.b_c2, d, a2, (int)Rc, ipw, act)
-      if (geo == 1) LAUNCH_FWD1(1); else if (geo == 3) LAUNCH_FWD1(3); else LAUNCH_FWD1(0);
+      if (mfma) k_conv5m_fwd<CM_IN4, 6><<<dim3(nwg, E), 256, ldm_f1, st>>>(Xc, 0, (long long)g.C * HW, g.W, 1, (long long)HW, g.C, g.H, g.W, 2, theta, g.k_c1, g.b_c1, d, a1, (int)Rc, ipw, act);
+      else if (geo == 1) LAUNCH_FWD1(1); else if (geo == 3) LAUNCH_FWD1(3); else LAUNCH_FWD1(0);
       k_avgpool2<<<blocks(B * (long long)n_p1), 256, 0, st>>>(a1, p1, B, g.H, g.W, 6);
-      if (geo == 1) LAUNCH_FWD2(2); else if (geo == 3) LAUNCH_FWD2(4); else LAUNCH_FWD2(0);
+      if (mfma) k_conv5m_fwd<CM_IN8, 16><<<dim3(nwg, E), 256, ldm_f2, st>>>(p1, Rc * (long long)n_p1, (long long)n_p1, g.wp1 * 6, 6, 1, 6, g.hp1, g.wp1, 0, theta, g.k_c2, g.b_c2, d, a2, (int)Rc, ipw, act);
+      else if (geo == 1) LAUNCH_FWD2(2); else if (geo == 3) LAUNCH_FWD2(4); else LAUNCH_FWD2(0);
 #undef LAUNCH_FWD1
 #undef LAUNCH_FWD2
     } else {
@@ -764,10 +778,13 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
 #define LAUNCH_DW2(GEO_) k_conv5_dw<16, GEO_><<<dim3(nwg, E), 256, lds_w2, st>>>(p1, Rc * (long long)n_p1, (long long)n_p1, g.wp1 * 6, 6, 1, 6, g.hp1, g.wp1, 0, dp2, a2, act, part2, (int)Rc, ipw)
 #define LAUNCH_DX(HO_, WO_) k_conv5_dx<6, 16, 1, HO_, WO_><<<dim3(nwg, E), 256, lds_x2, st>>>(dp2, a2, act, theta, g.k_c2, d, dp1, (int)Rc, g.h2, g.w2, ipw)
 #define LAUNCH_DW1(GEO_) k_conv5_dw<6, GEO_><<<dim3(nwg, E), 256, lds_w1, st>>>(Xc, 0, (long long)g.C * HW, g.W, 1, (long long)HW, g.C, g.H, g.W, 2, dp1, a1, act, part1, (int)Rc, ipw)
-      if (geo == 1) LAUNCH_DW2(2); else if (geo == 3) LAUNCH_DW2(4); else LAUNCH_DW2(0);
+      if (mfma) k_conv5m_dw<CM_IN8, 16><<<dim3(nwg, E), 256, ldm_w2, st>>>(p1, Rc * (long long)n_p1, (long long)n_p1, g.wp1 * 6, 6, 1, 6, g.hp1, g.wp1, 0, dp2, a2, act, part2, (int)Rc, ipw);
+      else if (geo == 1) LAUNCH_DW2(2); else if (geo == 3) LAUNCH_DW2(4); else LAUNCH_DW2(0);
       k_conv_reduce<<<dim3(10, E), 256, 0, st>>>(part2, (int)nwg, 2400, 16, slab, dp, g.k_c2, g.b_c2, acc);
-      if (geo == 1) LAUNCH_DX(12, 12); else if (geo == 3) LAUNCH_DX(10, 10); else LAUNCH_DX(0, 0);
-      if (geo == 1) LAUNCH_DW1(1); else if (geo == 3) LAUNCH_DW1(3); else LAUNCH_DW1(0);
+      if (mfma) k_conv5m_dx<6, 16><<<dim3(nwg, E), 256, ldm_x2, st>>>(dp2, a2, act, theta, g.k_c2, d, dp1, (int)Rc, g.h2, g.w2, ipw);
+      else if (geo == 1) LAUNCH_DX(12, 12); else if (geo == 3) LAUNCH_DX(10, 10); else LAUNCH_DX(0, 0);
+      if (mfma) k_conv5m_dw<CM_IN4, 6><<<dim3(nwg, E), 256, ldm_w1, st>>>(Xc, 0, (long long)g.C * HW, g.W, 1, (long long)HW, g.C, g.H, g.W, 2, dp1, a1, act, part1, (int)Rc, ipw);
+      else if (geo == 1) LAUNCH_DW1(1); else if (geo == 3) LAUNCH_DW1(3); else LAUNCH_DW1(0);
 #undef LAUNCH_DW2
 #undef LAUNCH_DX
 #undef LAUNCH_DW1
@@ -1120,8 +1137,8 @@ static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t s
     else if (nh == 3 && fq == 1) e = launch_w64<3, 1, true>(gp, fz, E, st);
     else if (fq == 2 && !fz.enabled) e = mile_launch_w64_split_fq2(nh, gp, E, st);   // mile_w64_fq2.hip
     HIP_TRY(e);
-  } else if (kernel == MILE_GRAD_LENET_F32) {
-    const int rc = run_lenet(s, theta, E, gp.X, gp.y, s->N, gp.slabs, gp.dp, gp.llpart, nullptr, 0, st);
+  } else if (kernel == MILE_GRAD_LENET_F32 || kernel == MILE_GRAD_LENET_BF16) {
+    const int rc = run_lenet(s, theta, E, gp.X, gp.y, s->N, gp.slabs, gp.dp, gp.llpart, nullptr, 0, st, kernel == MILE_GRAD_LENET_BF16);
     if (rc) return rc;
   } else if (kernel == MILE_GRAD_GEMM_F32) {
     const int rc = launch_grad_gemm(s, gp, E, st);
@@ -1333,9 +1350,10 @@ extern "C" int32_t mile_pointwise_loglik(mile_sampler *s, const float *theta, in
   pp.spec = s->ds; pp.theta = theta; pp.X = s->ev_X; pp.Xp = s->ev_Xp; pp.y = s->ev_y; pp.out = out;
   pp.N = (int)N; pp.Npad = Npad; pp.Fp = Fp; pp.R = generic_R(s->ds);
   const int kernel = resolved_kernel(s);
-  if (kernel == MILE_GRAD_LENET_F32) {
+  if (kernel == MILE_GRAD_LENET_F32 || kernel == MILE_GRAD_LENET_BF16) {
     for (int s0 = 0; s0 < S; s0 += 256) {
-      const int rc = run_lenet(s, theta + (size_t)s0 * s->ds.d, std::min(256, S - s0), s->ev_X, s->ev_y, (int)N, nullptr, 0, nullptr, out, s0, st);
+      const int rc = run_lenet(s, theta + (size_t)s0 * s->ds.d, std::min(256, S - s0), s->ev_X, s->ev_y, (int)N, nullptr, 0, nullptr, out, s0, st,
+                               kernel == MILE_GRAD_LENET_BF16);
       if (rc) return rc;
     }
     return MILE_OK;
@@ -1389,6 +1407,9 @@ int32_t mile_grad_launch_info(const mile_sampler *s, int32_t E, int32_t *grid_x,
     nm = "k_grad_w64";
     lds = nh == 2 ? (fq == 1 ? w64_lds_bytes<2, 1, true>() : w64_lds_bytes<2, 2, true>())
                   : (fq == 1 ? w64_lds_bytes<3, 1, true>() : w64_lds_bytes<3, 2, true>());
+  } else if (kernel == MILE_GRAD_LENET_BF16) {
+    nm = "k_conv5m_fwd/dx/dw (implicit-GEMM bf16 MFMA) + rocblas_sgemm_strided_batched (Dense)";
+    lds = (int)cm_lds_dw(CM_IN8, s->lg.hp1, s->lg.wp1, 0);
   } else if (kernel == MILE_GRAD_LENET_F32) {
     nm = "rocblas_sgemm_strided_batched+k_im2col5/k_col2im5/k_avgpool2";
     lds = 0;

@@ -1,0 +1,320 @@
+// LeNet convolutions on the gfx950 matrix pipe (MILE_GRAD_LENET_BF16; BASELINE config 5 names bf16):
+// implicit-GEMM 5x5 convolutions on v_mfma_f32_16x16x32_bf16, operands rounded to bf16 where they enter a product
+// (oracle/lenet_oracle.py logpost_and_grad_bf16), fp32 accumulation.  src/models/images/cnns.py:33-66.
+//
+// No im2col matrix anywhere: a workgroup = one particle x a range of images keeps one image's input as a bf16 tile in
+// LDS, pixel-major with the channels of a pixel contiguous (8 bytes = 4 channels per "slot": conv1 has <= 4 input
+// channels = 1 slot per pixel, conv2 has 6 -> 2 slots, the dZ tile of the input-gradient pass has 16 -> 4 slots).
+// A kernel tap and a slot's channels are one 8-byte LDS read at (pixel base + tap offset); the GEMM K index runs over
+// (tap, channel) in units of slots, so the "patch matrix" is only ever a set of addresses.
+//   forward / input gradient ("F" form):  D[m][pixel] = sum_{slot, j} Kop[m][slot][j] * tile[pixel + off(slot)][j]
+//       A = the particle's kernel (rows m = output channel, or input channel for the input gradient), held in registers
+//       for the whole workgroup; B = 8-byte tile reads; 16 pixels per MFMA, K = 32 = 8 slots.
+//   kernel gradient ("W" form):  dK[slot][j][co] = sum_{pixel} tile[pixel + off(slot)][j] * dz[pixel][co]
+//       both operands contract over pixels, i.e. are read transposed: ds_read_b64_tr_b16 (a 16-lane group hands in the
+//       addresses of 4 pixels x 4 slots and gets back, per lane, one (slot, channel) row of 4 pixels); 32 pixels per
+//       MFMA, 16 kernel rows (4 slots) x 16 output channels per accumulator; bias gradient = a ones row.
+// MFMA operand maps (cdna_hip_programming.md section 3): lane l holds A[row l & 15][k = 8 (l >> 4) + j],
+// B[k = 8 (l >> 4) + j][col l & 15], D[row 4 (l >> 4) + reg][col l & 15].
+// Everything that is not a convolution product (bias, activation and its derivative, pooling, the Dense layers, the
+// likelihood) is the fp32 code of mile_lenet.h; dZ = unpool(dP) * act'(A) is formed while staging, as there.
+#pragma once
+#include "mile_bf16_frag.h"
+#include "mile_lenet.h"
+
+typedef float cm_f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t cm_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t cm_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ cm_f32x4 cm_mfma(const bf16x8 a, const bf16x8 b, const cm_f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t cm_pack2(float lo, float hi) {   // two floats -> packed bf16 pair, round to nearest even
+  const bf16x2 v = {(bf16)lo, (bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+// Slot geometry.  PB = bytes per pixel of the tile; off(s, rowpix) = byte offset of slot s from the pixel base (rowpix =
+// pixels per tile row); tap(s) / c0(s) = kernel tap and first channel the slot stands for; NS slots in all.
+enum { CM_IN4 = 0, CM_IN8 = 1, CM_DZ16 = 2 };
+template <int MODE> struct CSlot;
+template <> struct CSlot<CM_IN4> {   // <= 4 input channels: slot = (kh, kw) with kw padded to 6 (kw = 5 is a zero tap)
+  static constexpr int NS = 30, PB = 8;
+  __device__ static int off(int s, int rowpix) { return ((s / 6) * rowpix + s % 6) * 8; }
+  __device__ static bool valid(int s) { return s < NS && s % 6 < 5; }
+  __device__ static int tap(int s) { return (s / 6) * 5 + s % 6; }
+  __device__ static int c0(int) { return 0; }
+};
+template <> struct CSlot<CM_IN8> {   // <= 8 input channels: slot = (tap, half)
+  static constexpr int NS = 50, PB = 16;
+  __device__ static int off(int s, int rowpix) { return (((s >> 1) / 5) * rowpix + (s >> 1) % 5) * 16 + 8 * (s & 1); }
+  __device__ static bool valid(int s) { return s < NS; }
+  __device__ static int tap(int s) { return s >> 1; }
+  __device__ static int c0(int s) { return 4 * (s & 1); }
+};
+template <> struct CSlot<CM_DZ16> {  // the dZ tile of the input-gradient pass, <= 16 channels: slot = (tap, quarter), taps look BACK
+  static constexpr int NS = 100, PB = 32;
+  __device__ static int off(int s, int rowpix) { return -(((s >> 2) / 5) * rowpix + (s >> 2) % 5) * 32 + 8 * (s & 3); }
+  __device__ static bool valid(int s) { return s < NS; }
+  __device__ static int tap(int s) { return s >> 2; }
+  __device__ static int c0(int s) { return 4 * (s & 3); }
+};
+
+// zero-padded bf16 input tile [Hp][Wp][PB / 2 channels] (+ 8 pixels of zero slack: the padded taps read past the last row)
+template <int MODE>
+__device__ __forceinline__ void cm_stage_input(char *tile, const float *src, long long sH, long long sW, long long sC, int CIN, int H, int W,
+                                               int pad, int tid) {
+  constexpr int CPX = CSlot<MODE>::PB / 2;
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+  for (int i = tid; i < Hp * Wp + 8; i += 256) {
+    const int yy = i / Wp, xx = i - yy * Wp;
+    const int h = yy - pad, w = xx - pad;
+    const bool in = i < Hp * Wp && h >= 0 && h < H && w >= 0 && w < W;
+    float v[CPX];
+#pragma unroll
+    for (int c = 0; c < CPX; ++c) v[c] = (in && c < CIN) ? src[h * sH + w * sW + c * sC] : 0.0f;
+    if constexpr (CPX == 4) {
+      *reinterpret_cast<cm_u32x2 *>(tile + (size_t)i * 8) = cm_u32x2{cm_pack2(v[0], v[1]), cm_pack2(v[2], v[3])};
+    } else {
+      *reinterpret_cast<cm_u32x4 *>(tile + (size_t)i * 16) =
+          cm_u32x4{cm_pack2(v[0], v[1]), cm_pack2(v[2], v[3]), cm_pack2(v[4], v[5]), cm_pack2(v[6], v[7])};
+    }
+  }
+}
+
+// The particle's kernel as the A operand of the F form: ka[c] = rows m (lane & 15), k-blocks 4c + (lane >> 4) = slots 2 blk, 2 blk + 1.
+// DX = false: rows are output channels, K[(tap * CIN + ci) * COUT + m];  DX = true: rows are input channels, K[(tap * CIN + m) * COUT + co].
+template <int MODE, int NMF, bool DX>
+__device__ __forceinline__ void cm_kernel_operand(const float *K, int CIN, int COUT, int lane, bf16x8 (&ka)[NMF]) {
+  using G = CSlot<MODE>;
+  const int m = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < NMF; ++c) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int s = 2 * (4 * c + g) + (j >> 2), ch = G::c0(s) + (j & 3);
+      bool ok = G::valid(s);
+      int idx;
+      if constexpr (DX) { ok = ok && m < CIN && ch < COUT; idx = (G::tap(s) * CIN + m) * COUT + ch; }
+      else { ok = ok && ch < CIN && m < COUT; idx = (G::tap(s) * CIN + ch) * COUT + m; }
+      v[j] = ok ? K[idx] : 0.0f;
+    }
+    const cm_u32x4 pk = {cm_pack2(v[0], v[1]), cm_pack2(v[2], v[3]), cm_pack2(v[4], v[5]), cm_pack2(v[6], v[7])};
+    ka[c] = __builtin_bit_cast(bf16x8, pk);
+  }
+}
+
+// one 16-pixel tile of the F form: 8-byte reads at base + so[c][0 / 1]
+template <int NMF>
+__device__ __forceinline__ cm_f32x4 cm_tile_f(const char *tile, int base, const int (&so)[NMF][2], const bf16x8 (&ka)[NMF]) {
+  cm_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int c = 0; c < NMF; ++c) {
+    const cm_u32x2 lo = *reinterpret_cast<const cm_u32x2 *>(tile + base + so[c][0]);
+    const cm_u32x2 hi = *reinterpret_cast<const cm_u32x2 *>(tile + base + so[c][1]);
+    const cm_u32x4 b = {lo[0], lo[1], hi[0], hi[1]};
+    acc = cm_mfma(ka[c], __builtin_bit_cast(bf16x8, b), acc);
+  }
+  return acc;
+}
+
+// out[e][b][y][x][co] = act(bias[co] + sum in[b][y+kh-pad][x+kw-pad][ci] K[kh][kw][ci][co]), NHWC fp32 (as k_conv5_fwd)
+template <int MODE, int COUT>
+__global__ __launch_bounds__(256) void k_conv5m_fwd(const float *in, long long sE, long long sB, long long sH, long long sW, long long sC,
+                                                    int CIN, int H, int W, int pad, const float *theta, int k_off, int b_off, int d, float *out,
+                                                    int R, int ipw, int activation) {
+  using G = CSlot<MODE>;
+  constexpr int NMF = ((G::NS + 1) / 2 + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) char cm_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e = blockIdx.y;
+  const int n16 = lane & 15, g = lane >> 4;
+  const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4, Wp = W + 2 * pad, npix = Ho * Wo;
+  bf16x8 ka[NMF];
+  cm_kernel_operand<MODE, NMF, false>(theta + (size_t)e * d + k_off, CIN, COUT, lane, ka);
+  int so[NMF][2];
+#pragma unroll
+  for (int c = 0; c < NMF; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int s = 2 * (4 * c + g) + u;
+      so[c][u] = s < G::NS ? G::off(s, Wp) : 0;
+    }
+  float bias4[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bias4[i] = 4 * g + i < COUT ? theta[(size_t)e * d + b_off + 4 * g + i] : 0.0f;
+  const int b0 = blockIdx.x * ipw, b1 = min(R, b0 + ipw);
+  for (int b = b0; b < b1; ++b) {
+    __syncthreads();
+    cm_stage_input<MODE>(cm_lds, in + (size_t)e * sE + (size_t)b * sB, sH, sW, sC, CIN, H, W, pad, tid);
+    __syncthreads();
+    float *dst = out + ((size_t)e * R + b) * npix * COUT;
+    for (int mt = wave; mt * 16 < npix; mt += 4) {
+      const int p = mt * 16 + n16, pc = min(p, npix - 1);
+      const int y = pc / Wo, x = pc - y * Wo;
+      const cm_f32x4 acc = cm_tile_f<NMF>(cm_lds, (y * Wp + x) * G::PB, so, ka);
+      if (p < npix && 4 * g < COUT) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = act_fwd(activation, acc[i] + bias4[i]);
+        float *o = dst + (size_t)p * COUT + 4 * g;
+        if constexpr (COUT % 4 == 0) {
+          *reinterpret_cast<cm_f32x4 *>(o) = cm_f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (4 * g + i < COUT) o[i] = v[i];
+        }
+      }
+    }
+  }
+}
+
+// bf16 dZ tile of one image with a zero halo: tile[(y + HALO) * Wt + x + HALO][16 channels], Wt = Wo + 2 HALO;
+// dz = unpool(dp) * act'(a) (mile_lenet.h dz_from_pool).  npix_alloc pixels are written (zeros outside the image).
+template <int COUT>
+__device__ __forceinline__ void cm_stage_dz(char *zt, const float *dp_img, const float *a_img, int Ho, int Wo, int halo, int npix_alloc,
+                                            int activation, int tid) {
+  const int Wt = Wo + 2 * halo, Ht = Ho + 2 * halo;
+  for (int i = tid; i < npix_alloc * 4; i += 256) {
+    const int q4 = i & 3, px = i >> 2;
+    const int yy = px / Wt, xx = px - yy * Wt;
+    const int y = yy - halo, x = xx - halo;
+    const bool in = yy < Ht && y >= 0 && y < Ho && x >= 0 && x < Wo;
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = (in && 4 * q4 + c < COUT) ? dz_from_pool(dp_img, a_img, y, x, 4 * q4 + c, Ho, Wo, COUT, activation) : 0.0f;
+    *reinterpret_cast<cm_u32x2 *>(zt + (size_t)px * 32 + 8 * q4) = cm_u32x2{cm_pack2(v[0], v[1]), cm_pack2(v[2], v[3])};
+  }
+}
+
+// VALID 5x5 conv, gradient w.r.t. the input (as k_conv5_dx): din[e][b][yi][xi][ci] = sum_{kh,kw,co} dz[yi-kh][xi-kw][co] K[kh][kw][ci][co]
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void k_conv5m_dx(const float *dp, const float *a, int activation, const float *theta, int k_off, int d,
+                                                   float *din, int R, int Ho, int Wo, int ipw) {
+  using G = CSlot<CM_DZ16>;
+  constexpr int NMF = ((G::NS + 1) / 2 + 3) / 4;
+  static_assert(COUT <= 16 && CIN <= 16, "one slot quartet / one MFMA row block");
+  extern __shared__ __attribute__((aligned(16))) char cm_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e = blockIdx.y;
+  const int n16 = lane & 15, g = lane >> 4;
+  const int H = Ho + 4, W = Wo + 4, Ht = Ho + 8, Wt = Wo + 8, npix = H * W;
+  bf16x8 ka[NMF];
+  cm_kernel_operand<CM_DZ16, NMF, true>(theta + (size_t)e * d + k_off, CIN, COUT, lane, ka);
+  int so[NMF][2];
+#pragma unroll
+  for (int c = 0; c < NMF; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int s = 2 * (4 * c + g) + u;
+      so[c][u] = s < G::NS ? G::off(s, Wt) : 0;
+    }
+  const int b0 = blockIdx.x * ipw, b1 = min(R, b0 + ipw);
+  for (int b = b0; b < b1; ++b) {
+    const size_t img = (size_t)e * R + b;
+    __syncthreads();
+    cm_stage_dz<COUT>(cm_lds, dp + img * (Ho / 2) * (Wo / 2) * COUT, a + img * Ho * Wo * COUT, Ho, Wo, 4, Ht * Wt, activation, tid);
+    __syncthreads();
+    float *dst = din + img * npix * CIN;
+    for (int mt = wave; mt * 16 < npix; mt += 4) {
+      const int p = mt * 16 + n16, pc = min(p, npix - 1);
+      const int yi = pc / W, xi = pc - yi * W;
+      const cm_f32x4 acc = cm_tile_f<NMF>(cm_lds, ((yi + 4) * Wt + xi + 4) * 32, so, ka);
+      if (p < npix) {
+        float *o = dst + (size_t)p * CIN + 4 * g;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (4 * g + i < CIN) o[i] = acc[i];
+      }
+    }
+  }
+}
+
+// Kernel / bias gradient of one image range (as k_conv5_dw): part[(e * nwg + wg) * (25*CIN*COUT + COUT) + ...]
+//   dK[kh][kw][ci][co] = sum_{b,y,x} in[b][y+kh-pad][x+kw-pad][ci] dz[b][y][x][co],  db[co] = sum dz
+template <int MODE, int COUT>
+__global__ __launch_bounds__(256) void k_conv5m_dw(const float *in, long long sE, long long sB, long long sH, long long sW, long long sC, int CIN,
+                                                   int H, int W, int pad, const float *dp, const float *a, int activation, float *part, int R,
+                                                   int ipw) {
+  using G = CSlot<MODE>;
+  constexpr int NMT = (G::NS + 3) / 4;            // accumulator tiles of 4 slots x 4 channels = 16 kernel rows
+  static_assert(COUT <= 16, "one MFMA column block");
+  extern __shared__ __attribute__((aligned(16))) char cm_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e = blockIdx.y;
+  const int n16 = lane & 15, g = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
+  const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4, Hp = H + 2 * pad, Wp = W + 2 * pad, npix = Ho * Wo;
+  const int npix32 = (npix + 31) / 32 * 32;
+  char *tile = cm_lds;                                              // (Hp * Wp + 8) pixels of PB bytes
+  char *zt = cm_lds + ((size_t)(Hp * Wp + 8) * G::PB + 15) / 16 * 16;   // [npix32][16] bf16, zero beyond the image
+  int so[NMT];
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt) so[mt] = 4 * mt + p4 < G::NS ? G::off(4 * mt + p4, Wp) : 0;
+  cm_f32x4 acc[NMT], accb = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt) acc[mt] = cm_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  const cm_u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
+  const int b0 = blockIdx.x * ipw, b1 = min(R, b0 + ipw);
+  for (int b = b0; b < b1; ++b) {
+    const size_t img = (size_t)e * R + b;
+    __syncthreads();
+    cm_stage_input<MODE>(tile, in + (size_t)e * sE + (size_t)b * sB, sH, sW, sC, CIN, H, W, pad, tid);
+    cm_stage_dz<COUT>(zt, dp + img * (Ho / 2) * (Wo / 2) * COUT, a + img * npix * COUT, Ho, Wo, 0, npix32, activation, tid);
+    __syncthreads();
+    for (int ch = wave; ch * 32 < npix; ch += 4) {
+      // this lane's two rows of the transposed reads: pixels P0 = 32 ch + 8 g + q and P0 + 4
+      const int P0 = 32 * ch + 8 * g + q, P1 = P0 + 4;
+      const int c0 = min(P0, npix - 1), c1 = min(P1, npix - 1);     // the dZ rows beyond the image are zero
+      const int y0 = c0 / Wo, x0 = c0 - y0 * Wo, y1 = c1 / Wo, x1 = c1 - y1 * Wo;
+      const int base0 = (y0 * Wp + x0) * G::PB, base1 = (y1 * Wp + x1) * G::PB;
+      const bf16x4 z0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, zt + P0 * 32 + 8 * p4));
+      const bf16x4 z1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, zt + P1 * 32 + 8 * p4));
+      const bf16x8 bz = __builtin_shufflevector(z0, z1, 0, 1, 2, 3, 4, 5, 6, 7);
+      accb = cm_mfma(ones, bz, accb);
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt) {
+        const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, tile + base0 + so[mt]));
+        const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, tile + base1 + so[mt]));
+        acc[mt] = cm_mfma(__builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7), bz, acc[mt]);
+      }
+    }
+  }
+  // the four waves' partial sums -> one: red[wave][tile][lane] through LDS (aliases the image tiles), fixed order
+  __syncthreads();
+  cm_f32x4 *red = reinterpret_cast<cm_f32x4 *>(cm_lds);
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt) red[(wave * (NMT + 1) + mt) * 64 + lane] = acc[mt];
+  red[(wave * (NMT + 1) + NMT) * 64 + lane] = accb;
+  __syncthreads();
+  float *dst = part + ((size_t)e * gridDim.x + blockIdx.x) * (25 * CIN * COUT + COUT);
+  for (int mt = wave; mt <= NMT; mt += 4) {
+    cm_f32x4 t = red[(0 * (NMT + 1) + mt) * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) t += red[(w * (NMT + 1) + mt) * 64 + lane];
+    if (n16 >= COUT) continue;
+    if (mt == NMT) {                         // ones row: every row of the tile is the column sum of dZ
+      if (g == 0) dst[25 * CIN * COUT + n16] = t[0];
+    } else {                                 // D[row 4 g + i][col n16]: slot 4 mt + g, channel c0 + i, output channel n16
+      const int s = 4 * mt + g;
+      if (G::valid(s)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (G::c0(s) + i < CIN) dst[(G::tap(s) * CIN + G::c0(s) + i) * COUT + n16] = t[i];
+      }
+    }
+  }
+}
+
+// LDS bytes of the three kernels for a geometry (host side)
+static inline size_t cm_lds_fwd(int mode, int H, int W, int pad) {
+  const int pb = mode == CM_IN4 ? 8 : 16;
+  return (size_t)((H + 2 * pad) * (W + 2 * pad) + 8) * pb;
+}
+static inline size_t cm_lds_dx(int Ho, int Wo) { return (size_t)(Ho + 8) * (Wo + 8) * 32; }
+static inline size_t cm_lds_dw(int mode, int H, int W, int pad) {
+  const int pb = mode == CM_IN4 ? 8 : 16, ns = mode == CM_IN4 ? 30 : 50;
+  const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4;
+  const size_t tiles = ((size_t)((H + 2 * pad) * (W + 2 * pad) + 8) * pb + 15) / 16 * 16 + (size_t)((Ho * Wo + 31) / 32 * 32) * 32;
+  const size_t red = (size_t)4 * ((ns + 3) / 4 + 1) * 64 * 16;
+  return tiles > red ? tiles : red;
+}

@@ -92,19 +92,24 @@ def _unpool(g: np.ndarray, H: int, W: int) -> np.ndarray:
     return out
 
 
-def forward(spec: LeNetSpec, theta: np.ndarray, X: np.ndarray, keep: bool = False):
-    """theta [E, d], X [N, C, H, W] -> out [E, N, out_dim] (and the intermediates for the backward pass)."""
+def _same(x):
+    return x
+
+
+def forward(spec: LeNetSpec, theta: np.ndarray, X: np.ndarray, keep: bool = False, q=_same):
+    """theta [E, d], X [N, C, H, W] -> out [E, N, out_dim] (and the intermediates for the backward pass).
+    q rounds the operands of the two convolutions (identity here; bfloat16 in logpost_and_grad_bf16)."""
     P = _unravel(spec, theta)
     E, N = theta.shape[0], X.shape[0]
     dt = theta.dtype
     x = np.transpose(X.astype(dt), (0, 2, 3, 1))                               # NHWC
-    xp = np.pad(x, ((0, 0), (2, 2), (2, 2), (0, 0)))
+    xp = np.pad(q(x), ((0, 0), (2, 2), (2, 2), (0, 0)))
     col1 = _patches(xp, 5).reshape(N * spec.height * spec.width, 25 * spec.channels)
-    z1 = np.einsum('nk,eko->eno', col1, P['core.conv1.kernel'].reshape(E, -1, 6)) + P['core.conv1.bias'][:, None, :]
+    z1 = np.einsum('nk,eko->eno', col1, q(P['core.conv1.kernel']).reshape(E, -1, 6)) + P['core.conv1.bias'][:, None, :]
     a1 = M._act(spec.activation, z1).reshape(E, N, spec.height, spec.width, 6)
     p1 = _pool(a1)
-    col2 = _patches(p1, 5).reshape(E, N * spec.h2 * spec.w2, 150)
-    z2 = col2 @ P['core.conv2.kernel'].reshape(E, 150, 16) + P['core.conv2.bias'][:, None, :]
+    col2 = _patches(q(p1), 5).reshape(E, N * spec.h2 * spec.w2, 150)
+    z2 = col2 @ q(P['core.conv2.kernel']).reshape(E, 150, 16) + P['core.conv2.bias'][:, None, :]
     a2 = M._act(spec.activation, z2).reshape(E, N, spec.h2, spec.w2, 16)
     p2 = _pool(a2).reshape(E, N, spec.flat)
     zf1 = p2 @ P['core.fc1.kernel'] + P['core.fc1.bias'][:, None, :]
@@ -117,10 +122,19 @@ def forward(spec: LeNetSpec, theta: np.ndarray, X: np.ndarray, keep: bool = Fals
     return out
 
 
-def logpost_and_grad(spec: LeNetSpec, theta: np.ndarray, X: np.ndarray, y: np.ndarray):
+def logpost_and_grad_bf16(spec: LeNetSpec, theta: np.ndarray, X: np.ndarray, y: np.ndarray):
+    """logpost_and_grad under the mixed-precision recipe of the MFMA convolution kernels (`lenet_bf16`, BASELINE config 5
+    names bf16): every operand of a CONVOLUTION product -- the layer's input, its kernel, and in the backward pass the
+    back-propagated dZ -- is rounded to bfloat16 where it enters the product; accumulation, bias, activation and its
+    derivative (from the un-rounded activations), pooling, the three Dense layers, likelihood and prior stay in the working
+    precision.  Checker for the bf16 HIP path; same citations as logpost_and_grad."""
+    return logpost_and_grad(spec, theta, X, y, q=M.bf16_round)
+
+
+def logpost_and_grad(spec: LeNetSpec, theta: np.ndarray, X: np.ndarray, y: np.ndarray, q=_same):
     """log_unnormalized_posterior and its gradient for an ensemble: theta [E, d] -> (logp [E], grad [E, d])."""
     E, N = theta.shape[0], X.shape[0]
-    out, c = forward(spec, theta, X, keep=True)
+    out, c = forward(spec, theta, X, keep=True, q=q)
     P = c['P']
     ll, dout = M.pointwise_loglik(spec, out, y)
     lp, gp = M.log_prior(spec, theta)
@@ -135,16 +149,16 @@ def logpost_and_grad(spec: LeNetSpec, theta: np.ndarray, X: np.ndarray, y: np.nd
     g['core.fc1.bias'] = d1.sum(axis=1)
     dp2 = (d1 @ np.swapaxes(P['core.fc1.kernel'], 1, 2)).reshape(E, N, spec.hp2, spec.wp2, 16)
     da2 = _unpool(dp2, spec.h2, spec.w2).reshape(E, N * spec.h2 * spec.w2, 16)
-    dz2 = da2 * M._act_grad(spec.activation, c['z2'], c['a2'].reshape(E, -1, 16))
+    dz2 = q(da2 * M._act_grad(spec.activation, c['z2'], c['a2'].reshape(E, -1, 16)))
     g['core.conv2.kernel'] = (np.swapaxes(c['col2'], 1, 2) @ dz2).reshape(E, 5, 5, 6, 16)
     g['core.conv2.bias'] = dz2.sum(axis=1)
-    dcol2 = (dz2 @ np.swapaxes(P['core.conv2.kernel'].reshape(E, 150, 16), 1, 2)).reshape(E, N, spec.h2, spec.w2, 5, 5, 6)
+    dcol2 = (dz2 @ np.swapaxes(q(P['core.conv2.kernel']).reshape(E, 150, 16), 1, 2)).reshape(E, N, spec.h2, spec.w2, 5, 5, 6)
     dp1 = np.zeros((E, N, spec.hp1, spec.wp1, 6), dtype=theta.dtype)
     for kh in range(5):
         for kw in range(5):
             dp1[:, :, kh:kh + spec.h2, kw:kw + spec.w2, :] += dcol2[:, :, :, :, kh, kw, :]
     da1 = _unpool(dp1, spec.height, spec.width).reshape(E, N * spec.height * spec.width, 6)
-    dz1 = da1 * M._act_grad(spec.activation, c['z1'], c['a1'].reshape(E, -1, 6))
+    dz1 = q(da1 * M._act_grad(spec.activation, c['z1'], c['a1'].reshape(E, -1, 6)))
     g['core.conv1.kernel'] = np.einsum('nk,eno->eko', c['col1'], dz1).reshape(E, 5, 5, spec.channels, 6)
     g['core.conv1.bias'] = dz1.sum(axis=1)
     grad = np.concatenate([g[n].reshape(E, -1) for n, _, _ in spec.leaves()], axis=1)

@@ -13,14 +13,14 @@ def LN():
     return lenet_oracle
 
 
-def _engine(ospec, prob):
+def _engine(ospec, prob, kernel='auto'):
     from mile_amd import LeNetSpec
     from mile_amd.engine import Engine
     spec = LeNetSpec(ospec.channels, ospec.height, ospec.width, ospec.out_dim, activation=ospec.activation, task=ospec.task,
                      prior=ospec.prior, prior_loc=ospec.prior_loc, prior_scale=ospec.prior_scale)
     assert spec.n_params == ospec.n_params
     assert [(n, o, tuple(s)) for n, o, s in spec.leaves()] == [(n, o, tuple(s)) for n, o, s in ospec.leaves()]
-    return Engine(spec, torch.from_numpy(prob['X']), torch.from_numpy(prob['y']), device='cuda:0')
+    return Engine(spec, torch.from_numpy(prob['X']), torch.from_numpy(prob['y']), device='cuda:0', grad_kernel=kernel)
 
 
 def _relerr(a, b):
@@ -52,6 +52,48 @@ def test_lenet_logpost_grad_matches_oracle(LN, C, H, W, K, act, task, prior, N, 
     for name, off, shape in ospec.leaves():
         n = int(np.prod(shape))
         assert _relerr(g[:, off:off + n], g_ref[:, off:off + n]) < 5e-5, name
+
+
+@pytest.mark.parametrize('C,H,W,K,act,task,prior,N,E', CASES + [(4, 20, 24, 4, 'relu', 'classification', 'Normal', 19, 2)])
+def test_lenet_mfma_convolutions_match_the_bf16_recipe(LN, C, H, W, K, act, task, prior, N, E):
+    """`lenet_bf16`: the five convolution products as implicit GEMMs on v_mfma_f32_16x16x32_bf16 with bf16-rounded operands,
+    against the oracle's restatement of that recipe (`logpost_and_grad_bf16`, fp64 accumulation).  The two round fp32- vs
+    fp64-computed activations, so a value on a rounding boundary may flip (2^-8 of ONE operand): 3e-3 per leaf, 1e-3 in norm.
+    Against the full-precision oracle the distance is what bf16 operands cost (a few per cent at these tiny N), bounded loosely here."""
+    ospec = LN.LeNetSpec(C, H, W, K, activation=act, task=task, prior=prior, prior_scale=0.7 if prior == 'Laplace' else 1.0)
+    prob = LN.synthetic_problem(ospec, N, E, seed=3)
+    th64 = prob['theta0'].astype(np.float64)
+    lp_ref, g_ref = LN.logpost_and_grad_bf16(ospec, th64, prob['X'], prob['y'])
+    lp_full, g_full = LN.logpost_and_grad(ospec, th64, prob['X'], prob['y'])
+    eng = _engine(ospec, prob, 'lenet_bf16')
+    assert eng.grad_kernel == 'lenet_bf16'
+    lp, g = eng.logpost_grad(torch.from_numpy(prob['theta0']))
+    torch.cuda.synchronize()
+    g = g.cpu().numpy()
+    assert _relerr(lp.cpu().numpy(), lp_ref) < 1e-4
+    for name, off, shape in ospec.leaves():
+        n = int(np.prod(shape))
+        assert _relerr(g[:, off:off + n], g_ref[:, off:off + n]) < 3e-3, name
+    nrm = np.linalg.norm(g.astype(np.float64) - g_ref, axis=1) / np.linalg.norm(g_ref, axis=1)
+    assert nrm.max() < 1e-3, nrm
+    full = np.linalg.norm(g.astype(np.float64) - g_full, axis=1) / np.linalg.norm(g_full, axis=1)
+    assert full.max() < 1e-1, full
+    # image chunks accumulate (forced to 4 images per chunk), and evaluation runs the same forward kernels
+    import os
+    os.environ['MILE_GEMM_ROWS'] = '4'
+    try:
+        lp2, g2 = _engine(ospec, prob, 'lenet_bf16').logpost_grad(torch.from_numpy(prob['theta0']))
+    finally:
+        del os.environ['MILE_GEMM_ROWS']
+    assert _relerr(g2.cpu().numpy(), g) < 2e-5 and _relerr(lp2.cpu().numpy(), lp.cpu().numpy()) < 1e-5
+    pw = eng.pointwise_loglik(torch.from_numpy(prob['theta0']), torch.from_numpy(prob['X']), torch.from_numpy(prob['y']))
+    ll_rows = M_pointwise(LN, ospec, th64, prob)
+    assert np.abs(pw.cpu().numpy() - ll_rows).max() < 2e-3 * max(1.0, np.abs(ll_rows).max())
+
+
+def M_pointwise(LN, ospec, th64, prob):
+    out = LN.forward(ospec, th64, prob['X'], q=LN.M.bf16_round)
+    return LN.M.pointwise_loglik(ospec, out, prob['y'])[0]
 
 
 @pytest.mark.parametrize('gemm_form', [False, True])
