@@ -659,7 +659,7 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
   const size_t nwg_max = (R + ipw - 1) / ipw;
   const size_t n_part1 = direct && grad ? (size_t)E * nwg_max * (25 * g.C * 6 + 6) : 0;
   const size_t n_part2 = direct && grad ? (size_t)E * nwg_max * (2400 + 16) : 0;
-  const size_t need = R * ((size_t)E * per + shared) + n_part1 + n_part2;
+  const size_t need = R * ((size_t)E * per + shared) + n_part1 + n_part2 + 128;   // + the arrays' alignment padding
   if (need > s->gemm_ws_floats) {
     if (s->gemm_ws) (void)hipFree(s->gemm_ws);
     s->gemm_ws = nullptr; s->gemm_ws_floats = 0;
@@ -677,7 +677,7 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
   }
   const size_t ER = (size_t)E * R;
   float *q = s->gemm_ws;
-  auto take = [&](size_t n) { float *r = q; q += n; return r; };
+  auto take = [&](size_t n) { float *r = q; q += (n + 3) / 4 * 4; return r; };   // every array 16-byte aligned (vector loads in the conv kernels)
   float *col1 = take(R * shared), *a1 = take(ER * n_a1), *p1 = take(ER * n_p1), *col2 = take(direct ? 0 : ER * n_col2), *a2 = take(ER * n_a2);
   float *p2 = take(ER * n_p2), *f1 = take(ER * 120), *f2 = take(ER * 84), *out = take(ER * g.K);
   float *df2 = nullptr, *df1 = nullptr, *dp2 = nullptr, *dz2 = nullptr, *dp1 = nullptr, *dz1 = nullptr;

@@ -19,10 +19,13 @@
 // Everything that is not a convolution product (bias, activation and its derivative, pooling, the Dense layers, the
 // likelihood) is the fp32 code of mile_lenet.h; dZ = unpool(dP) * act'(A) is formed while staging, as there.
 #pragma once
+#include <type_traits>
+
 #include "mile_bf16_frag.h"
 #include "mile_lenet.h"
 
 typedef float cm_f32x4 __attribute__((ext_vector_type(4)));
+typedef float cm_f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t cm_u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t cm_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -33,6 +36,9 @@ __device__ __forceinline__ uint32_t cm_pack2(float lo, float hi) {   // two floa
   const bf16x2 v = {(bf16)lo, (bf16)hi};
   return __builtin_bit_cast(uint32_t, v);
 }
+
+// p / w for 0 <= p < 2^20 with inv = 1.0f / w (exact: the quotient's distance from an integer is >= 1 / (2 w) >> the float error)
+__device__ __forceinline__ int cm_div(int p, float inv) { return (int)(((float)p + 0.5f) * inv); }
 
 // Slot geometry.  PB = bytes per pixel of the tile; off(s, rowpix) = byte offset of slot s from the pixel base (rowpix =
 // pixels per tile row); tap(s) / c0(s) = kernel tap and first channel the slot stands for; NS slots in all.
@@ -60,24 +66,46 @@ template <> struct CSlot<CM_DZ16> {  // the dZ tile of the input-gradient pass, 
   __device__ static int c0(int s) { return 4 * (s & 3); }
 };
 
-// zero-padded bf16 input tile [Hp][Wp][PB / 2 channels] (+ 8 pixels of zero slack: the padded taps read past the last row)
+// zero-padded bf16 input tile [Hp][Wp][PB / 2 channels] (+ 8 pixels of zero slack: the padded taps read past the last row).
+// U pixels per thread and pass with all their global loads issued before the first conversion: as a plain loop every
+// iteration waited out its own loads' latency (16 serial HBM round trips per image were most of the kernels' time).
 template <int MODE>
 __device__ __forceinline__ void cm_stage_input(char *tile, const float *src, long long sH, long long sW, long long sC, int CIN, int H, int W,
                                                int pad, int tid) {
-  constexpr int CPX = CSlot<MODE>::PB / 2;
-  const int Hp = H + 2 * pad, Wp = W + 2 * pad;
-  for (int i = tid; i < Hp * Wp + 8; i += 256) {
-    const int yy = i / Wp, xx = i - yy * Wp;
-    const int h = yy - pad, w = xx - pad;
-    const bool in = i < Hp * Wp && h >= 0 && h < H && w >= 0 && w < W;
-    float v[CPX];
+  constexpr int CPX = CSlot<MODE>::PB / 2, U = 3;
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad, n = Hp * Wp + 8;
+  const float inv_wp = 1.0f / (float)Wp;
+  const bool nhwc2 = sC == 1 && sW == CIN && (CIN & 1) == 0 && (sH & 1) == 0 && ((uintptr_t)src & 7) == 0;   // channel pairs as 8-byte loads
+  for (int i0 = tid; i0 < n; i0 += 256 * U) {
+    float v[U][CPX];
 #pragma unroll
-    for (int c = 0; c < CPX; ++c) v[c] = (in && c < CIN) ? src[h * sH + w * sW + c * sC] : 0.0f;
-    if constexpr (CPX == 4) {
-      *reinterpret_cast<cm_u32x2 *>(tile + (size_t)i * 8) = cm_u32x2{cm_pack2(v[0], v[1]), cm_pack2(v[2], v[3])};
-    } else {
-      *reinterpret_cast<cm_u32x4 *>(tile + (size_t)i * 16) =
-          cm_u32x4{cm_pack2(v[0], v[1]), cm_pack2(v[2], v[3]), cm_pack2(v[4], v[5]), cm_pack2(v[6], v[7])};
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + 256 * u;
+      const int yy = cm_div(i, inv_wp), xx = i - yy * Wp;
+      const int h = yy - pad, w = xx - pad;
+      const bool in = i < Hp * Wp && h >= 0 && h < H && w >= 0 && w < W;
+      const float *px = src + (in ? h * sH + w * sW : 0);
+      if (nhwc2) {
+#pragma unroll
+        for (int c = 0; c < CPX; c += 2) {
+          const cm_f32x2 t = (in && c < CIN) ? *reinterpret_cast<const cm_f32x2 *>(px + c) : cm_f32x2{0.0f, 0.0f};
+          v[u][c] = t[0]; v[u][c + 1] = t[1];
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < CPX; ++c) v[u][c] = (in && c < CIN) ? px[c * sC] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + 256 * u;
+      if (i >= n) continue;
+      if constexpr (CPX == 4) {
+        *reinterpret_cast<cm_u32x2 *>(tile + (size_t)i * 8) = cm_u32x2{cm_pack2(v[u][0], v[u][1]), cm_pack2(v[u][2], v[u][3])};
+      } else {
+        *reinterpret_cast<cm_u32x4 *>(tile + (size_t)i * 16) =
+            cm_u32x4{cm_pack2(v[u][0], v[u][1]), cm_pack2(v[u][2], v[u][3]), cm_pack2(v[u][4], v[u][5]), cm_pack2(v[u][6], v[u][7])};
+      }
     }
   }
 }
@@ -105,18 +133,69 @@ __device__ __forceinline__ void cm_kernel_operand(const float *K, int CIN, int C
   }
 }
 
-// one 16-pixel tile of the F form: 8-byte reads at base + so[c][0 / 1]
-template <int NMF>
-__device__ __forceinline__ cm_f32x4 cm_tile_f(const char *tile, int base, const int (&so)[NMF][2], const bf16x8 (&ka)[NMF]) {
-  cm_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+// All 16-pixel tiles of one image in the F form.  A wave takes tile PAIRS (t, t + 4), t = wave, wave + 8, ...: two independent
+// accumulator chains, and the tile reads of the next group of four k-blocks -- or of the next pair -- are in flight while the
+// current group's MFMAs run (register double buffer, parities resolved at compile time).  Left to the compiler the loop was
+// read -> s_waitcnt lgkmcnt(0) -> MFMA per k-block through ONE fragment register set: an LDS round trip per MFMA.
+// base_of(pixel) = byte offset of the pixel's tile entry; epi(tile index, acc) stores one tile.
+template <int NMF, class BaseFn, class EpiFn>
+__device__ __forceinline__ void cm_image_f(const char *tile, int npix, int wave, int n16, const int (&so)[NMF][2], const bf16x8 (&ka)[NMF],
+                                           BaseFn base_of, EpiFn epi) {
+  constexpr int NG = (NMF + 3) / 4;
+  cm_u32x2 lo[2][2][4], hi[2][2][4];                    // [buffer][tile of the pair][k-block of the group]
+  auto load = [&](const int bA, const int bB, const int grp, cm_u32x2 (&l)[2][4], cm_u32x2 (&h)[2][4]) {
 #pragma unroll
-  for (int c = 0; c < NMF; ++c) {
-    const cm_u32x2 lo = *reinterpret_cast<const cm_u32x2 *>(tile + base + so[c][0]);
-    const cm_u32x2 hi = *reinterpret_cast<const cm_u32x2 *>(tile + base + so[c][1]);
-    const cm_u32x4 b = {lo[0], lo[1], hi[0], hi[1]};
-    acc = cm_mfma(ka[c], __builtin_bit_cast(bf16x8, b), acc);
+    for (int u = 0; u < 4; ++u) {
+      const int c = 4 * grp + u;
+      if (c < NMF) {
+        l[0][u] = *reinterpret_cast<const cm_u32x2 *>(tile + bA + so[c][0]);
+        h[0][u] = *reinterpret_cast<const cm_u32x2 *>(tile + bA + so[c][1]);
+        l[1][u] = *reinterpret_cast<const cm_u32x2 *>(tile + bB + so[c][0]);
+        h[1][u] = *reinterpret_cast<const cm_u32x2 *>(tile + bB + so[c][1]);
+      }
+    }
+  };
+  int t0 = wave;
+  if (t0 * 16 >= npix) return;
+  int bA = base_of(min(t0 * 16 + n16, npix - 1)), bB = base_of(min((t0 + 4) * 16 + n16, npix - 1));
+  load(bA, bB, 0, lo[0], hi[0]);
+  bool more = true;
+  auto pair = [&](auto par_c) {
+    constexpr int PAR = decltype(par_c)::value;
+    const int nt0 = t0 + 8;
+    more = nt0 * 16 < npix;
+    int nA = 0, nB = 0;
+    if (more) { nA = base_of(min(nt0 * 16 + n16, npix - 1)); nB = base_of(min((nt0 + 4) * 16 + n16, npix - 1)); }
+    cm_f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int grp = 0; grp < NG; ++grp) {
+      const int cur = (PAR + grp) & 1, nxt = cur ^ 1;
+      if (grp + 1 < NG) load(bA, bB, grp + 1, lo[nxt], hi[nxt]);
+      else if (more) load(nA, nB, 0, lo[nxt], hi[nxt]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = 4 * grp + u;
+        if (c < NMF) {
+          const cm_u32x4 f0 = {lo[cur][0][u][0], lo[cur][0][u][1], hi[cur][0][u][0], hi[cur][0][u][1]};
+          const cm_u32x4 f1 = {lo[cur][1][u][0], lo[cur][1][u][1], hi[cur][1][u][0], hi[cur][1][u][1]};
+          acc0 = cm_mfma(ka[c], __builtin_bit_cast(bf16x8, f0), acc0);
+          acc1 = cm_mfma(ka[c], __builtin_bit_cast(bf16x8, f1), acc1);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    epi(t0, acc0);
+    if ((t0 + 4) * 16 < npix) epi(t0 + 4, acc1);
+    bA = nA; bB = nB; t0 = nt0;
+  };
+  while (more) {
+    pair(std::integral_constant<int, 0>{});
+    if constexpr (NG % 2 == 1) {
+      if (!more) break;
+      pair(std::integral_constant<int, 1>{});
+    }
   }
-  return acc;
 }
 
 // out[e][b][y][x][co] = act(bias[co] + sum in[b][y+kh-pad][x+kw-pad][ci] K[kh][kw][ci][co]), NHWC fp32 (as k_conv5_fwd)
@@ -143,48 +222,88 @@ __global__ __launch_bounds__(256) void k_conv5m_fwd(const float *in, long long s
   float bias4[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) bias4[i] = 4 * g + i < COUT ? theta[(size_t)e * d + b_off + 4 * g + i] : 0.0f;
+  const float inv_wo = 1.0f / (float)Wo;
   const int b0 = blockIdx.x * ipw, b1 = min(R, b0 + ipw);
   for (int b = b0; b < b1; ++b) {
     __syncthreads();
     cm_stage_input<MODE>(cm_lds, in + (size_t)e * sE + (size_t)b * sB, sH, sW, sC, CIN, H, W, pad, tid);
     __syncthreads();
     float *dst = out + ((size_t)e * R + b) * npix * COUT;
-    for (int mt = wave; mt * 16 < npix; mt += 4) {
-      const int p = mt * 16 + n16, pc = min(p, npix - 1);
-      const int y = pc / Wo, x = pc - y * Wo;
-      const cm_f32x4 acc = cm_tile_f<NMF>(cm_lds, (y * Wp + x) * G::PB, so, ka);
-      if (p < npix && 4 * g < COUT) {
-        float v[4];
+    cm_image_f<NMF>(cm_lds, npix, wave, n16, so, ka,
+      [&](const int pc) { const int y = cm_div(pc, inv_wo), x = pc - y * Wo; return (y * Wp + x) * G::PB; },
+      [&](const int mt, const cm_f32x4 acc) {
+        const int p = mt * 16 + n16;
+        if (p < npix && 4 * g < COUT) {
+          float v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = act_fwd(activation, acc[i] + bias4[i]);
-        float *o = dst + (size_t)p * COUT + 4 * g;
-        if constexpr (COUT % 4 == 0) {
-          *reinterpret_cast<cm_f32x4 *>(o) = cm_f32x4{v[0], v[1], v[2], v[3]};
-        } else {
+          for (int i = 0; i < 4; ++i) v[i] = act_fwd(activation, acc[i] + bias4[i]);
+          float *o = dst + (size_t)p * COUT + 4 * g;
+          if constexpr (COUT % 4 == 0) {
+            *reinterpret_cast<cm_f32x4 *>(o) = cm_f32x4{v[0], v[1], v[2], v[3]};
+          } else {
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (4 * g + i < COUT) o[i] = v[i];
+            for (int i = 0; i < 4; ++i)
+              if (4 * g + i < COUT) o[i] = v[i];
+          }
         }
-      }
-    }
+      });
   }
 }
 
 // bf16 dZ tile of one image with a zero halo: tile[(y + HALO) * Wt + x + HALO][16 channels], Wt = Wo + 2 HALO;
-// dz = unpool(dp) * act'(a) (mile_lenet.h dz_from_pool).  npix_alloc pixels are written (zeros outside the image).
+// dz = unpool(dp) * act'(a): dz[y][x][c] = (avg-pool backward: dp[y/2][x/2][c] / 4, zero on the cropped border) * act'(a[y][x][c])
+// (mile_lenet.h dz_from_pool).  npix_alloc pixels are written (zeros outside the image).  One pixel per thread and pass, its
+// channels as 8- / 16-byte loads, U pixels' loads in flight (see cm_stage_input); a / dp rows are 8-byte aligned (COUT even).
 template <int COUT>
 __device__ __forceinline__ void cm_stage_dz(char *zt, const float *dp_img, const float *a_img, int Ho, int Wo, int halo, int npix_alloc,
                                             int activation, int tid) {
-  const int Wt = Wo + 2 * halo, Ht = Ho + 2 * halo;
-  for (int i = tid; i < npix_alloc * 4; i += 256) {
-    const int q4 = i & 3, px = i >> 2;
-    const int yy = px / Wt, xx = px - yy * Wt;
-    const int y = yy - halo, x = xx - halo;
-    const bool in = yy < Ht && y >= 0 && y < Ho && x >= 0 && x < Wo;
-    float v[4];
+  static_assert(COUT % 2 == 0 && COUT <= 16, "channel pairs");
+  constexpr int U = 4, VW = COUT % 4 == 0 ? 4 : 2;
+  const int Wt = Wo + 2 * halo, Ht = Ho + 2 * halo, Hq = Ho / 2, Wq = Wo / 2;
+  const float inv_wt = 1.0f / (float)Wt;
+  for (int i0 = tid; i0 < npix_alloc; i0 += 256 * U) {
+    float av[U][COUT], gv[U][COUT];
+    bool in[U];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) v[c] = (in && 4 * q4 + c < COUT) ? dz_from_pool(dp_img, a_img, y, x, 4 * q4 + c, Ho, Wo, COUT, activation) : 0.0f;
-    *reinterpret_cast<cm_u32x2 *>(zt + (size_t)px * 32 + 8 * q4) = cm_u32x2{cm_pack2(v[0], v[1]), cm_pack2(v[2], v[3])};
+    for (int u = 0; u < U; ++u) {
+      const int px = i0 + 256 * u;
+      const int yy = cm_div(px, inv_wt), xx = px - yy * Wt;
+      const int y = yy - halo, x = xx - halo;
+      in[u] = px < npix_alloc && yy < Ht && y >= 0 && y < Ho && x >= 0 && x < Wo;
+      const bool pin = in[u] && y < 2 * Hq && x < 2 * Wq;
+      const float *ap = a_img + (size_t)(in[u] ? y * Wo + x : 0) * COUT;
+      const float *gp = dp_img + (size_t)(pin ? (y >> 1) * Wq + (x >> 1) : 0) * COUT;
+#pragma unroll
+      for (int c = 0; c < COUT; c += VW) {
+        if constexpr (VW == 4) {
+          const cm_f32x4 ta = *reinterpret_cast<const cm_f32x4 *>(ap + c);
+          const cm_f32x4 tg = pin ? *reinterpret_cast<const cm_f32x4 *>(gp + c) : cm_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { av[u][c + k] = ta[k]; gv[u][c + k] = tg[k]; }
+        } else {
+          const cm_f32x2 ta = *reinterpret_cast<const cm_f32x2 *>(ap + c);
+          const cm_f32x2 tg = pin ? *reinterpret_cast<const cm_f32x2 *>(gp + c) : cm_f32x2{0.0f, 0.0f};
+          av[u][c] = ta[0]; av[u][c + 1] = ta[1]; gv[u][c] = tg[0]; gv[u][c + 1] = tg[1];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int px = i0 + 256 * u;
+      if (px >= npix_alloc) continue;
+      uint32_t pk[8];
+#pragma unroll
+      for (int c = 0; c < 16; c += 2) {
+        float v0 = 0.0f, v1 = 0.0f;
+        if (c < COUT) {
+          v0 = in[u] ? 0.25f * gv[u][c] * act_bwd(activation, av[u][c]) : 0.0f;
+          v1 = in[u] ? 0.25f * gv[u][c + 1] * act_bwd(activation, av[u][c + 1]) : 0.0f;
+        }
+        pk[c >> 1] = cm_pack2(v0, v1);
+      }
+      *reinterpret_cast<cm_u32x4 *>(zt + (size_t)px * 32) = cm_u32x4{pk[0], pk[1], pk[2], pk[3]};
+      *reinterpret_cast<cm_u32x4 *>(zt + (size_t)px * 32 + 16) = cm_u32x4{pk[4], pk[5], pk[6], pk[7]};
+    }
   }
 }
 
@@ -209,6 +328,7 @@ __global__ __launch_bounds__(256) void k_conv5m_dx(const float *dp, const float 
       const int s = 2 * (4 * c + g) + u;
       so[c][u] = s < G::NS ? G::off(s, Wt) : 0;
     }
+  const float inv_w = 1.0f / (float)W;
   const int b0 = blockIdx.x * ipw, b1 = min(R, b0 + ipw);
   for (int b = b0; b < b1; ++b) {
     const size_t img = (size_t)e * R + b;
@@ -216,17 +336,17 @@ __global__ __launch_bounds__(256) void k_conv5m_dx(const float *dp, const float 
     cm_stage_dz<COUT>(cm_lds, dp + img * (Ho / 2) * (Wo / 2) * COUT, a + img * Ho * Wo * COUT, Ho, Wo, 4, Ht * Wt, activation, tid);
     __syncthreads();
     float *dst = din + img * npix * CIN;
-    for (int mt = wave; mt * 16 < npix; mt += 4) {
-      const int p = mt * 16 + n16, pc = min(p, npix - 1);
-      const int yi = pc / W, xi = pc - yi * W;
-      const cm_f32x4 acc = cm_tile_f<NMF>(cm_lds, ((yi + 4) * Wt + xi + 4) * 32, so, ka);
-      if (p < npix) {
-        float *o = dst + (size_t)p * CIN + 4 * g;
+    cm_image_f<NMF>(cm_lds, npix, wave, n16, so, ka,
+      [&](const int pc) { const int yi = cm_div(pc, inv_w), xi = pc - yi * W; return ((yi + 4) * Wt + xi + 4) * 32; },
+      [&](const int mt, const cm_f32x4 acc) {
+        const int p = mt * 16 + n16;
+        if (p < npix) {
+          float *o = dst + (size_t)p * CIN + 4 * g;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (4 * g + i < CIN) o[i] = acc[i];
-      }
-    }
+          for (int i = 0; i < 4; ++i)
+            if (4 * g + i < CIN) o[i] = acc[i];
+        }
+      });
   }
 }
 
@@ -252,6 +372,7 @@ __global__ __launch_bounds__(256) void k_conv5m_dw(const float *in, long long sE
   cm_f32x4 acc[NMT], accb = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int mt = 0; mt < NMT; ++mt) acc[mt] = cm_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  const float inv_wo = 1.0f / (float)Wo;
   const cm_u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
   const int b0 = blockIdx.x * ipw, b1 = min(R, b0 + ipw);
@@ -261,21 +382,61 @@ __global__ __launch_bounds__(256) void k_conv5m_dw(const float *in, long long sE
     cm_stage_input<MODE>(tile, in + (size_t)e * sE + (size_t)b * sB, sH, sW, sC, CIN, H, W, pad, tid);
     cm_stage_dz<COUT>(zt, dp + img * (Ho / 2) * (Wo / 2) * COUT, a + img * npix * COUT, Ho, Wo, 0, npix32, activation, tid);
     __syncthreads();
-    for (int ch = wave; ch * 32 < npix; ch += 4) {
-      // this lane's two rows of the transposed reads: pixels P0 = 32 ch + 8 g + q and P0 + 4
+    // chunks of 32 pixels: ch = wave, wave + 4, ...  The fragments of the next group of four accumulator tiles -- or of the next
+    // chunk's first group and its dZ fragment -- are in flight while the current group's MFMAs run (see cm_image_f).
+    constexpr int NG = (NMT + 3) / 4;
+    static_assert(NG % 2 == 0, "the register double buffer returns to buffer 0 at every chunk");
+    bf16x4 a0[2][4], a1[2][4];
+    auto addr = [&](const int ch, int &bs0, int &bs1, int &zo0, int &zo1) {
+      // this lane's two rows of the transposed reads: pixels P0 = 32 ch + 8 g + q and P0 + 4 (dZ rows beyond the image are zero)
       const int P0 = 32 * ch + 8 * g + q, P1 = P0 + 4;
-      const int c0 = min(P0, npix - 1), c1 = min(P1, npix - 1);     // the dZ rows beyond the image are zero
-      const int y0 = c0 / Wo, x0 = c0 - y0 * Wo, y1 = c1 / Wo, x1 = c1 - y1 * Wo;
-      const int base0 = (y0 * Wp + x0) * G::PB, base1 = (y1 * Wp + x1) * G::PB;
-      const bf16x4 z0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, zt + P0 * 32 + 8 * p4));
-      const bf16x4 z1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, zt + P1 * 32 + 8 * p4));
-      const bf16x8 bz = __builtin_shufflevector(z0, z1, 0, 1, 2, 3, 4, 5, 6, 7);
-      accb = cm_mfma(ones, bz, accb);
+      const int c0 = min(P0, npix - 1), c1 = min(P1, npix - 1);
+      const int y0 = cm_div(c0, inv_wo), x0 = c0 - y0 * Wo, y1 = cm_div(c1, inv_wo), x1 = c1 - y1 * Wo;
+      bs0 = (y0 * Wp + x0) * G::PB; bs1 = (y1 * Wp + x1) * G::PB;
+      zo0 = P0 * 32 + 8 * p4; zo1 = P1 * 32 + 8 * p4;
+    };
+    auto load_z = [&](const int zo0, const int zo1) {
+      const bf16x4 z0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, zt + zo0));
+      const bf16x4 z1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, zt + zo1));
+      return __builtin_shufflevector(z0, z1, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto load_a = [&](const int bs0, const int bs1, const int grp, bf16x4 (&f0)[4], bf16x4 (&f1)[4]) {
 #pragma unroll
-      for (int mt = 0; mt < NMT; ++mt) {
-        const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, tile + base0 + so[mt]));
-        const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, tile + base1 + so[mt]));
-        acc[mt] = cm_mfma(__builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7), bz, acc[mt]);
+      for (int u = 0; u < 4; ++u) {
+        const int mt = 4 * grp + u;
+        if (mt < NMT) {
+          f0[u] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, tile + bs0 + so[mt]));
+          f1[u] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, tile + bs1 + so[mt]));
+        }
+      }
+    };
+    int ch = wave;
+    if (ch * 32 < npix) {
+      int bs0, bs1, zo0, zo1;
+      addr(ch, bs0, bs1, zo0, zo1);
+      bf16x8 bz = load_z(zo0, zo1);
+      load_a(bs0, bs1, 0, a0[0], a1[0]);
+      for (bool more = true; more;) {
+        const int nch = ch + 4;
+        more = nch * 32 < npix;
+        int nb0 = 0, nb1 = 0, nz0 = 0, nz1 = 0;
+        if (more) addr(nch, nb0, nb1, nz0, nz1);
+        bf16x8 bzn = bz;
+#pragma unroll
+        for (int grp = 0; grp < NG; ++grp) {
+          const int cur = grp & 1, nxt = cur ^ 1;
+          if (grp + 1 < NG) load_a(bs0, bs1, grp + 1, a0[nxt], a1[nxt]);
+          else if (more) { bzn = load_z(nz0, nz1); load_a(nb0, nb1, 0, a0[nxt], a1[nxt]); }
+          __builtin_amdgcn_sched_barrier(0);
+          if (grp == 0) accb = cm_mfma(ones, bz, accb);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int mt = 4 * grp + u;
+            if (mt < NMT) acc[mt] = cm_mfma(__builtin_shufflevector(a0[cur][u], a1[cur][u], 0, 1, 2, 3, 4, 5, 6, 7), bz, acc[mt]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        bz = bzn; bs0 = nb0; bs1 = nb1; ch = nch;
       }
     }
   }
