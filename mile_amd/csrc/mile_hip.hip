@@ -646,7 +646,7 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
   const int geo = (g.C == 3 && g.H == 32 && g.W == 32) ? 1 : (g.C == 1 && g.H == 28 && g.W == 28) ? 3 : 0;
   const bool direct = getenv("MILE_LENET_GEMM") == nullptr && g.C <= 16 && lds_max <= 150 * 1024;
   // MILE_GRAD_LENET_BF16: the five convolution launches on the bf16 matrix pipe (mile_lenet_mfma.h), everything else as below
-  const size_t ldm_f1 = cm_lds_fwd(CM_IN4, g.H, g.W, 2), ldm_f2 = cm_lds_fwd(CM_IN8, g.hp1, g.wp1, 0), ldm_x2 = cm_lds_dx(g.h2, g.w2);
+  const size_t ldm_f1 = cm_lds_fwd(CM_IN4, g.H, g.W, 2, g.C, 6), ldm_f2 = cm_lds_fwd(CM_IN8, g.hp1, g.wp1, 0, 6, 16), ldm_x2 = cm_lds_dx(g.h2, g.w2, 6, 16);
   const size_t ldm_w1 = cm_lds_dw(CM_IN4, g.H, g.W, 2), ldm_w2 = cm_lds_dw(CM_IN8, g.hp1, g.wp1, 0);
   if (mfma && (!direct || g.C > 4 || std::max({ldm_f1, ldm_f2, ldm_x2, ldm_w1, ldm_w2}) > 150 * 1024))
     return fail(MILE_ERR_INVALID, "LENET_BF16 needs <= 4 image channels and an image that fits the LDS tiles");
@@ -718,10 +718,11 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
     if (direct) {
 #define LAUNCH_FWD1(GEO_) k_conv5_fwd<6, GEO_><<<dim3(nwg, E), 256, lds_f1, st>>>(Xc, 0, (long long)g.C * HW, g.W, 1, (long long)HW, g.C, g.H, g.W, 2, theta, g.k_c1, g.b_c1, d, a1, (int)Rc, ipw, act)
 #define LAUNCH_FWD2(GEO_) k_conv5_fwd<16, GEO_><<<dim3(nwg, E), 256, lds_f2, st>>>(p1, Rc * (long long)n_p1, (long long)n_p1, g.wp1 * 6, 6, 1, 6, g.hp1, g.wp1, 0, theta, g.k_c2, g.b_c2, d, a2, (int)Rc, ipw, act)
-      if (mfma) k_conv5m_fwd<CM_IN4, 6><<<dim3(nwg, E), 256, ldm_f1, st>>>(Xc, 0, (long long)g.C * HW, g.W, 1, (long long)HW, g.C, g.H, g.W, 2, theta, g.k_c1, g.b_c1, d, a1, (int)Rc, ipw, act);
+      // MFMA form: the pooled activations come out of the convolution's own epilogue; evaluation skips the full-size ones
+      if (mfma) k_conv5m_fwd<CM_IN4, 6><<<dim3(nwg, E), 256, ldm_f1, st>>>(Xc, 0, (long long)g.C * HW, g.W, 1, (long long)HW, g.C, g.H, g.W, 2, theta, g.k_c1, g.b_c1, d, grad ? a1 : nullptr, p1, (int)Rc, ipw, act);
       else if (geo == 1) LAUNCH_FWD1(1); else if (geo == 3) LAUNCH_FWD1(3); else LAUNCH_FWD1(0);
-      k_avgpool2<<<blocks(B * (long long)n_p1), 256, 0, st>>>(a1, p1, B, g.H, g.W, 6);
-      if (mfma) k_conv5m_fwd<CM_IN8, 16><<<dim3(nwg, E), 256, ldm_f2, st>>>(p1, Rc * (long long)n_p1, (long long)n_p1, g.wp1 * 6, 6, 1, 6, g.hp1, g.wp1, 0, theta, g.k_c2, g.b_c2, d, a2, (int)Rc, ipw, act);
+      if (!mfma) k_avgpool2<<<blocks(B * (long long)n_p1), 256, 0, st>>>(a1, p1, B, g.H, g.W, 6);
+      if (mfma) k_conv5m_fwd<CM_IN8, 16><<<dim3(nwg, E), 256, ldm_f2, st>>>(p1, Rc * (long long)n_p1, (long long)n_p1, g.wp1 * 6, 6, 1, 6, g.hp1, g.wp1, 0, theta, g.k_c2, g.b_c2, d, grad ? a2 : nullptr, p2, (int)Rc, ipw, act);
       else if (geo == 1) LAUNCH_FWD2(2); else if (geo == 3) LAUNCH_FWD2(4); else LAUNCH_FWD2(0);
 #undef LAUNCH_FWD1
 #undef LAUNCH_FWD2
@@ -734,7 +735,7 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
       if (fwd(g.k_c2, 150, 16, col2, M2 * 150, M2, a2)) return fail(MILE_ERR_HIP, "rocblas sgemm (conv2) failed");
       bias_act(a2, g.b_c2, 16, M2, 1);
     }
-    k_avgpool2<<<blocks(B * (long long)n_p2), 256, 0, st>>>(a2, p2, B, g.h2, g.w2, 16);
+    if (!mfma) k_avgpool2<<<blocks(B * (long long)n_p2), 256, 0, st>>>(a2, p2, B, g.h2, g.w2, 16);
     if (fwd(g.k_f1, g.flat, 120, p2, Rc * g.flat, Rc, f1)) return fail(MILE_ERR_HIP, "rocblas sgemm (fc1) failed");
     bias_act(f1, g.b_f1, 120, Rc, 1);
     if (fwd(g.k_f2, 120, 84, f1, Rc * 120, Rc, f2)) return fail(MILE_ERR_HIP, "rocblas sgemm (fc2) failed");

@@ -19,6 +19,7 @@
 // Everything that is not a convolution product (bias, activation and its derivative, pooling, the Dense layers, the
 // likelihood) is the fp32 code of mile_lenet.h; dZ = unpool(dP) * act'(A) is formed while staging, as there.
 #pragma once
+#include <algorithm>
 #include <type_traits>
 
 #include "mile_bf16_frag.h"
@@ -112,9 +113,15 @@ __device__ __forceinline__ void cm_stage_input(char *tile, const float *src, lon
 
 // The particle's kernel as the A operand of the F form: ka[c] = rows m (lane & 15), k-blocks 4c + (lane >> 4) = slots 2 blk, 2 blk + 1.
 // DX = false: rows are output channels, K[(tap * CIN + ci) * COUT + m];  DX = true: rows are input channels, K[(tap * CIN + m) * COUT + co].
+// K is read through an LDS copy (Ksh, 25 * CIN * COUT floats, aliasing the image tile): the gather below is 8 NMF scalar reads per
+// lane, which as global loads cost the workgroup more than the images it then processes.  Ends with a barrier-free state: the
+// caller's image loop starts with __syncthreads() before it overwrites the tile.
 template <int MODE, int NMF, bool DX>
-__device__ __forceinline__ void cm_kernel_operand(const float *K, int CIN, int COUT, int lane, bf16x8 (&ka)[NMF]) {
+__device__ __forceinline__ void cm_kernel_operand(const float *Kg, float *K, int CIN, int COUT, int tid, bf16x8 (&ka)[NMF]) {
   using G = CSlot<MODE>;
+  for (int i = tid; i < 25 * CIN * COUT; i += 256) K[i] = Kg[i];
+  __syncthreads();
+  const int lane = tid & 63;
   const int m = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int c = 0; c < NMF; ++c) {
@@ -137,9 +144,9 @@ __device__ __forceinline__ void cm_kernel_operand(const float *K, int CIN, int C
 // accumulator chains, and the tile reads of the next group of four k-blocks -- or of the next pair -- are in flight while the
 // current group's MFMAs run (register double buffer, parities resolved at compile time).  Left to the compiler the loop was
 // read -> s_waitcnt lgkmcnt(0) -> MFMA per k-block through ONE fragment register set: an LDS round trip per MFMA.
-// base_of(pixel) = byte offset of the pixel's tile entry; epi(tile index, acc) stores one tile.
+// base_of(t) = byte offset of this lane's pixel of tile t in the LDS image; epi(t, acc) stores one tile (all lanes call it).
 template <int NMF, class BaseFn, class EpiFn>
-__device__ __forceinline__ void cm_image_f(const char *tile, int npix, int wave, int n16, const int (&so)[NMF][2], const bf16x8 (&ka)[NMF],
+__device__ __forceinline__ void cm_image_f(const char *tile, int ntiles, int wave, const int (&so)[NMF][2], const bf16x8 (&ka)[NMF],
                                            BaseFn base_of, EpiFn epi) {
   constexpr int NG = (NMF + 3) / 4;
   cm_u32x2 lo[2][2][4], hi[2][2][4];                    // [buffer][tile of the pair][k-block of the group]
@@ -156,16 +163,16 @@ __device__ __forceinline__ void cm_image_f(const char *tile, int npix, int wave,
     }
   };
   int t0 = wave;
-  if (t0 * 16 >= npix) return;
-  int bA = base_of(min(t0 * 16 + n16, npix - 1)), bB = base_of(min((t0 + 4) * 16 + n16, npix - 1));
+  if (t0 >= ntiles) return;
+  int bA = base_of(t0), bB = base_of(min(t0 + 4, ntiles - 1));
   load(bA, bB, 0, lo[0], hi[0]);
   bool more = true;
   auto pair = [&](auto par_c) {
     constexpr int PAR = decltype(par_c)::value;
     const int nt0 = t0 + 8;
-    more = nt0 * 16 < npix;
+    more = nt0 < ntiles;
     int nA = 0, nB = 0;
-    if (more) { nA = base_of(min(nt0 * 16 + n16, npix - 1)); nB = base_of(min((nt0 + 4) * 16 + n16, npix - 1)); }
+    if (more) { nA = base_of(nt0); nB = base_of(min(nt0 + 4, ntiles - 1)); }
     cm_f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int grp = 0; grp < NG; ++grp) {
@@ -186,7 +193,7 @@ __device__ __forceinline__ void cm_image_f(const char *tile, int npix, int wave,
       __builtin_amdgcn_sched_barrier(0);
     }
     epi(t0, acc0);
-    if ((t0 + 4) * 16 < npix) epi(t0 + 4, acc1);
+    if (t0 + 4 < ntiles) epi(t0 + 4, acc1);         // wave-uniform
     bA = nA; bB = nB; t0 = nt0;
   };
   while (more) {
@@ -198,19 +205,23 @@ __device__ __forceinline__ void cm_image_f(const char *tile, int npix, int wave,
   }
 }
 
-// out[e][b][y][x][co] = act(bias[co] + sum in[b][y+kh-pad][x+kw-pad][ci] K[kh][kw][ci][co]), NHWC fp32 (as k_conv5_fwd)
+// out[e][b][y][x][co] = act(bias[co] + sum in[b][y+kh-pad][x+kw-pad][ci] K[kh][kw][ci][co]), NHWC fp32 (as k_conv5_fwd), and
+// pool[e][b][y/2][x/2][co] = its 2 x 2 average (avg_pool VALID, k_avgpool2) from the same registers: an MFMA tile is a 2 x 8 block
+// of output pixels (lane n: row n >> 3, column n & 7), so a pooling window is lanes {n, n^1, n^8, n^9} of one 16-lane group.
+// out may be null (evaluation needs the pooled activations only).
 template <int MODE, int COUT>
 __global__ __launch_bounds__(256) void k_conv5m_fwd(const float *in, long long sE, long long sB, long long sH, long long sW, long long sC,
                                                     int CIN, int H, int W, int pad, const float *theta, int k_off, int b_off, int d, float *out,
-                                                    int R, int ipw, int activation) {
+                                                    float *pool, int R, int ipw, int activation) {
   using G = CSlot<MODE>;
   constexpr int NMF = ((G::NS + 1) / 2 + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) char cm_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e = blockIdx.y;
   const int n16 = lane & 15, g = lane >> 4;
   const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4, Wp = W + 2 * pad, npix = Ho * Wo;
+  const int Hq = Ho / 2, Wq = Wo / 2, TX = (Wo + 7) / 8, ntiles = ((Ho + 1) / 2) * TX;
   bf16x8 ka[NMF];
-  cm_kernel_operand<MODE, NMF, false>(theta + (size_t)e * d + k_off, CIN, COUT, lane, ka);
+  cm_kernel_operand<MODE, NMF, false>(theta + (size_t)e * d + k_off, reinterpret_cast<float *>(cm_lds), CIN, COUT, tid, ka);
   int so[NMF][2];
 #pragma unroll
   for (int c = 0; c < NMF; ++c)
@@ -222,28 +233,51 @@ __global__ __launch_bounds__(256) void k_conv5m_fwd(const float *in, long long s
   float bias4[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) bias4[i] = 4 * g + i < COUT ? theta[(size_t)e * d + b_off + 4 * g + i] : 0.0f;
-  const float inv_wo = 1.0f / (float)Wo;
+  const float inv_tx = 1.0f / (float)TX;
+  const int dy = n16 >> 3, dx = n16 & 7;
   const int b0 = blockIdx.x * ipw, b1 = min(R, b0 + ipw);
   for (int b = b0; b < b1; ++b) {
     __syncthreads();
     cm_stage_input<MODE>(cm_lds, in + (size_t)e * sE + (size_t)b * sB, sH, sW, sC, CIN, H, W, pad, tid);
     __syncthreads();
-    float *dst = out + ((size_t)e * R + b) * npix * COUT;
-    cm_image_f<NMF>(cm_lds, npix, wave, n16, so, ka,
-      [&](const int pc) { const int y = cm_div(pc, inv_wo), x = pc - y * Wo; return (y * Wp + x) * G::PB; },
-      [&](const int mt, const cm_f32x4 acc) {
-        const int p = mt * 16 + n16;
-        if (p < npix && 4 * g < COUT) {
-          float v[4];
+    float *dst = out ? out + ((size_t)e * R + b) * npix * COUT : nullptr;
+    float *pdst = pool + ((size_t)e * R + b) * Hq * Wq * COUT;
+    cm_image_f<NMF>(cm_lds, ntiles, wave, so, ka,
+      [&](const int t) {
+        const int ty = cm_div(t, inv_tx), tx = t - ty * TX;
+        const int y = min(2 * ty + dy, Ho - 1), x = min(8 * tx + dx, Wo - 1);
+        return (y * Wp + x) * G::PB;
+      },
+      [&](const int t, const cm_f32x4 acc) {
+        const int ty = cm_div(t, inv_tx), tx = t - ty * TX;
+        const int y = 2 * ty + dy, x = 8 * tx + dx;
+        float v[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = act_fwd(activation, acc[i] + bias4[i]);
-          float *o = dst + (size_t)p * COUT + 4 * g;
+        for (int i = 0; i < 4; ++i) v[i] = act_fwd(activation, acc[i] + bias4[i]);
+        if (dst && y < Ho && x < Wo && 4 * g < COUT) {
+          float *o = dst + (size_t)(y * Wo + x) * COUT + 4 * g;
           if constexpr (COUT % 4 == 0) {
             *reinterpret_cast<cm_f32x4 *>(o) = cm_f32x4{v[0], v[1], v[2], v[3]};
           } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
               if (4 * g + i < COUT) o[i] = v[i];
+          }
+        }
+        float s4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {            // window sum in the order of k_avgpool2: (a00 + a01) + (a10 + a11)
+          const float h2 = v[i] + __shfl_xor(v[i], 1);
+          s4[i] = 0.25f * (h2 + __shfl_xor(h2, 8));
+        }
+        if (dy == 0 && (dx & 1) == 0 && y < 2 * Hq && x < 2 * Wq && 4 * g < COUT) {
+          float *o = pdst + (size_t)((y >> 1) * Wq + (x >> 1)) * COUT + 4 * g;
+          if constexpr (COUT % 4 == 0) {
+            *reinterpret_cast<cm_f32x4 *>(o) = cm_f32x4{s4[0], s4[1], s4[2], s4[3]};
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (4 * g + i < COUT) o[i] = s4[i];
           }
         }
       });
@@ -319,7 +353,7 @@ __global__ __launch_bounds__(256) void k_conv5m_dx(const float *dp, const float 
   const int n16 = lane & 15, g = lane >> 4;
   const int H = Ho + 4, W = Wo + 4, Ht = Ho + 8, Wt = Wo + 8, npix = H * W;
   bf16x8 ka[NMF];
-  cm_kernel_operand<CM_DZ16, NMF, true>(theta + (size_t)e * d + k_off, CIN, COUT, lane, ka);
+  cm_kernel_operand<CM_DZ16, NMF, true>(theta + (size_t)e * d + k_off, reinterpret_cast<float *>(cm_lds), CIN, COUT, tid, ka);
   int so[NMF][2];
 #pragma unroll
   for (int c = 0; c < NMF; ++c)
@@ -336,8 +370,12 @@ __global__ __launch_bounds__(256) void k_conv5m_dx(const float *dp, const float 
     cm_stage_dz<COUT>(cm_lds, dp + img * (Ho / 2) * (Wo / 2) * COUT, a + img * Ho * Wo * COUT, Ho, Wo, 4, Ht * Wt, activation, tid);
     __syncthreads();
     float *dst = din + img * npix * CIN;
-    cm_image_f<NMF>(cm_lds, npix, wave, n16, so, ka,
-      [&](const int pc) { const int yi = cm_div(pc, inv_w), xi = pc - yi * W; return ((yi + 4) * Wt + xi + 4) * 32; },
+    cm_image_f<NMF>(cm_lds, (npix + 15) / 16, wave, so, ka,
+      [&](const int t) {
+        const int pc = min(t * 16 + n16, npix - 1);
+        const int yi = cm_div(pc, inv_w), xi = pc - yi * W;
+        return ((yi + 4) * Wt + xi + 4) * 32;
+      },
       [&](const int mt, const cm_f32x4 acc) {
         const int p = mt * 16 + n16;
         if (p < npix) {
@@ -467,11 +505,11 @@ __global__ __launch_bounds__(256) void k_conv5m_dw(const float *in, long long sE
 }
 
 // LDS bytes of the three kernels for a geometry (host side)
-static inline size_t cm_lds_fwd(int mode, int H, int W, int pad) {
+static inline size_t cm_lds_fwd(int mode, int H, int W, int pad, int CIN, int COUT) {
   const int pb = mode == CM_IN4 ? 8 : 16;
-  return (size_t)((H + 2 * pad) * (W + 2 * pad) + 8) * pb;
+  return std::max((size_t)((H + 2 * pad) * (W + 2 * pad) + 8) * pb, (size_t)25 * CIN * COUT * 4);
 }
-static inline size_t cm_lds_dx(int Ho, int Wo) { return (size_t)(Ho + 8) * (Wo + 8) * 32; }
+static inline size_t cm_lds_dx(int Ho, int Wo, int CIN, int COUT) { return std::max((size_t)(Ho + 8) * (Wo + 8) * 32, (size_t)25 * CIN * COUT * 4); }
 static inline size_t cm_lds_dw(int mode, int H, int W, int pad) {
   const int pb = mode == CM_IN4 ? 8 : 16, ns = mode == CM_IN4 ? 30 : 50;
   const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4;
