@@ -699,6 +699,7 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
       attr_done = true;
     }
   }
+  const int cm_dbg = getenv("MILE_CM_SKIP") ? atoi(getenv("MILE_CM_SKIP")) : 0;   // dev: timing knobs of k_conv5m_fwd
   const float one = 1.0f, zero = 0.0f;
   auto blocks = [](long long n) { return (unsigned)std::min<long long>((n + 255) / 256, 65535); };
   // row-major C[rows x fout] = A[rows x fin] W[fin x fout] per batch entry; W from theta (+ offset), batch stride d
@@ -719,10 +720,10 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
 #define LAUNCH_FWD1(GEO_) k_conv5_fwd<6, GEO_><<<dim3(nwg, E), 256, lds_f1, st>>>(Xc, 0, (long long)g.C * HW, g.W, 1, (long long)HW, g.C, g.H, g.W, 2, theta, g.k_c1, g.b_c1, d, a1, (int)Rc, ipw, act)
 #define LAUNCH_FWD2(GEO_) k_conv5_fwd<16, GEO_><<<dim3(nwg, E), 256, lds_f2, st>>>(p1, Rc * (long long)n_p1, (long long)n_p1, g.wp1 * 6, 6, 1, 6, g.hp1, g.wp1, 0, theta, g.k_c2, g.b_c2, d, a2, (int)Rc, ipw, act)
       // MFMA form: the pooled activations come out of the convolution's own epilogue; evaluation skips the full-size ones
-      if (mfma) k_conv5m_fwd<CM_IN4, 6><<<dim3(nwg, E), 256, ldm_f1, st>>>(Xc, 0, (long long)g.C * HW, g.W, 1, (long long)HW, g.C, g.H, g.W, 2, theta, g.k_c1, g.b_c1, d, grad ? a1 : nullptr, p1, (int)Rc, ipw, act);
+      if (mfma) k_conv5m_fwd<CM_IN4, 6><<<dim3(nwg, E), 256, ldm_f1, st>>>(Xc, 0, (long long)g.C * HW, g.W, 1, (long long)HW, g.C, g.H, g.W, 2, theta, g.k_c1, g.b_c1, d, grad ? a1 : nullptr, p1, (int)Rc, ipw, act, cm_dbg);
       else if (geo == 1) LAUNCH_FWD1(1); else if (geo == 3) LAUNCH_FWD1(3); else LAUNCH_FWD1(0);
       if (!mfma) k_avgpool2<<<blocks(B * (long long)n_p1), 256, 0, st>>>(a1, p1, B, g.H, g.W, 6);
-      if (mfma) k_conv5m_fwd<CM_IN8, 16><<<dim3(nwg, E), 256, ldm_f2, st>>>(p1, Rc * (long long)n_p1, (long long)n_p1, g.wp1 * 6, 6, 1, 6, g.hp1, g.wp1, 0, theta, g.k_c2, g.b_c2, d, grad ? a2 : nullptr, p2, (int)Rc, ipw, act);
+      if (mfma) k_conv5m_fwd<CM_IN8, 16><<<dim3(nwg, E), 256, ldm_f2, st>>>(p1, Rc * (long long)n_p1, (long long)n_p1, g.wp1 * 6, 6, 1, 6, g.hp1, g.wp1, 0, theta, g.k_c2, g.b_c2, d, grad ? a2 : nullptr, p2, (int)Rc, ipw, act, cm_dbg);
       else if (geo == 1) LAUNCH_FWD2(2); else if (geo == 3) LAUNCH_FWD2(4); else LAUNCH_FWD2(0);
 #undef LAUNCH_FWD1
 #undef LAUNCH_FWD2

@@ -212,7 +212,8 @@ __device__ __forceinline__ void cm_image_f(const char *tile, int ntiles, int wav
 template <int MODE, int COUT>
 __global__ __launch_bounds__(256) void k_conv5m_fwd(const float *in, long long sE, long long sB, long long sH, long long sW, long long sC,
                                                     int CIN, int H, int W, int pad, const float *theta, int k_off, int b_off, int d, float *out,
-                                                    float *pool, int R, int ipw, int activation) {
+                                                    float *pool, int R, int ipw, int activation, int dbg = 0) {
+  // dbg (MILE_CM_SKIP, timing experiments only -- results are wrong): 1 no full-size store, 2 no pooled store, 4 no MFMA loop, 8 no staging
   using G = CSlot<MODE>;
   constexpr int NMF = ((G::NS + 1) / 2 + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) char cm_lds[];
@@ -238,10 +239,11 @@ __global__ __launch_bounds__(256) void k_conv5m_fwd(const float *in, long long s
   const int b0 = blockIdx.x * ipw, b1 = min(R, b0 + ipw);
   for (int b = b0; b < b1; ++b) {
     __syncthreads();
-    cm_stage_input<MODE>(cm_lds, in + (size_t)e * sE + (size_t)b * sB, sH, sW, sC, CIN, H, W, pad, tid);
+    if (!(dbg & 8) || b == b0) cm_stage_input<MODE>(cm_lds, in + (size_t)e * sE + (size_t)b * sB, sH, sW, sC, CIN, H, W, pad, tid);
     __syncthreads();
-    float *dst = out ? out + ((size_t)e * R + b) * npix * COUT : nullptr;
+    float *dst = out && !(dbg & 1) ? out + ((size_t)e * R + b) * npix * COUT : nullptr;
     float *pdst = pool + ((size_t)e * R + b) * Hq * Wq * COUT;
+    if (dbg & 4) continue;
     cm_image_f<NMF>(cm_lds, ntiles, wave, so, ka,
       [&](const int t) {
         const int ty = cm_div(t, inv_tx), tx = t - ty * TX;
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256) void k_conv5m_fwd(const float *in, long long s
           const float h2 = v[i] + __shfl_xor(v[i], 1);
           s4[i] = 0.25f * (h2 + __shfl_xor(h2, 8));
         }
-        if (dy == 0 && (dx & 1) == 0 && y < 2 * Hq && x < 2 * Wq && 4 * g < COUT) {
+        if (!(dbg & 2) && dy == 0 && (dx & 1) == 0 && y < 2 * Hq && x < 2 * Wq && 4 * g < COUT) {
           float *o = pdst + (size_t)((y >> 1) * Wq + (x >> 1)) * COUT + 4 * g;
           if constexpr (COUT % 4 == 0) {
             *reinterpret_cast<cm_f32x4 *>(o) = cm_f32x4{s4[0], s4[1], s4[2], s4[3]};

@@ -141,6 +141,47 @@ def test_lenet_steps_and_pointwise_loglik_match_oracle(LN, oracle):
     assert np.abs(pw.cpu().numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
 
 
+def test_full_size_properties_config5_lenet(LN):
+    """BASELINE config 5 at its full ensemble (CIFAR-shaped LeNet, E = 256 particles; 1 000 images keep the test in seconds) on the
+    MFMA convolution path: agreement with the fp32 direct-convolution path at the bf16 recipe's cost, additivity over images,
+    permutation equivariance over particles (bit-exact), determinism and unit momentum through MCLMC steps (d = 83 126 takes the
+    two-pass update)."""
+    ospec = LN.LeNetSpec(3, 32, 32, 10)
+    N, E = 1000, 256
+    prob = LN.synthetic_problem(ospec, N, E, seed=0)
+    th = torch.from_numpy(prob['theta0'])
+    bf = _engine(ospec, prob, 'lenet_bf16')
+    lp1, g1 = bf.logpost_grad(th)
+    f32 = _engine(ospec, prob, 'lenet_f32')
+    lp2, g2 = f32.logpost_grad(th[:16])
+    assert _relerr(lp1[:16].cpu().numpy(), lp2.cpu().numpy()) < 2e-3
+    rel = ((g1[:16] - g2).norm(dim=1) / g2.norm(dim=1)).max().item()
+    assert rel < 1e-1, rel     # what bf16 operands cost at a random initialisation (4.5 % here; B3: 2-5 %)
+    # two particles against the oracle's restatement of the recipe
+    lo, go = LN.logpost_and_grad_bf16(ospec, prob['theta0'][:2].astype(np.float64), prob['X'], prob['y'])
+    assert _relerr(lp1[:2].cpu().numpy(), lo) < 1e-4
+    assert ((g1[:2].cpu().double() - torch.from_numpy(go)).norm(dim=1) / torch.from_numpy(go).norm(dim=1)).max().item() < 2e-3
+    # additivity over images (every image is rounded on its own; halves add up to fp32 summation order)
+    h = 504
+    half = lambda sl: _engine(ospec, dict(prob, X=prob['X'][sl], y=prob['y'][sl]), 'lenet_bf16').logpost_grad(th)
+    a, b = half(slice(0, h)), half(slice(h, N))
+    prior_g = -th.cuda()
+    assert _relerr((a[1] + b[1] - prior_g).cpu().numpy(), g1.cpu().numpy()) < 5e-5
+    # particles are independent: permuting theta's rows permutes the outputs bit for bit
+    perm = torch.randperm(E, generator=torch.Generator().manual_seed(1))
+    lp3, g3 = bf.logpost_grad(th[perm])
+    assert torch.equal(lp3.cpu(), lp1.cpu()[perm]) and torch.equal(g3.cpu(), g1.cpu()[perm])
+    # steps
+    ids = torch.arange(E, dtype=torch.int32)
+    eps, L = torch.full((E,), 1e-3), torch.full((E,), 1.0)
+    s0 = bf.init(th, seed=5, particle_ids=ids)
+    s1, info, kept = bf.step(s0, eps, L, n_steps=4, seed=5, n_thinning=2, particle_ids=ids)
+    s1b, info_b, _ = bf.step(s0, eps, L, n_steps=4, seed=5, n_thinning=2, particle_ids=ids)
+    assert torch.equal(s1.position, s1b.position) and torch.equal(info.energy_change, info_b.energy_change)
+    assert (s1.momentum.double().norm(dim=1) - 1).abs().max().item() < 1e-5
+    assert kept.shape == (2, E, ospec.n_params) and torch.isfinite(kept).all() and torch.isfinite(info.energy_change).all()
+
+
 def test_train_cli_lenet_yaml(tmp_path):
     """The YAML surface with `model: LeNet` and image data (config 5 shape, scaled down)."""
     import subprocess, sys, yaml
