@@ -18,7 +18,7 @@ about a second in total) and the MEDIAN repetition is reported, so a short regio
 driver passes --steps 20: 3 ms) is not dominated by clock ramp and first-launch effects.
 
 Prints ONE JSON line on rank 0.  `value` = particles x steps / wall seconds over all ranks.
-The default run adds BASELINE configs[2] (B3) as a bounded secondary leg inside the same line.
+The default run adds BASELINE configs[2..4] (B3, B4, B5) as bounded secondary legs inside the same line.
 """
 from __future__ import annotations
 
@@ -57,7 +57,16 @@ WORKLOADS = {
                text='B4: covertype-shaped N=232404 F=54, FCN hidden_structure [256,256,256,256,7] relu, softmax head, '
                     'StandardNormal prior, d=213255, 128 particles per GPU (of 1024 over 8); layer-wise MFMA GEMMs (k_mm3), '
                     'fp32-faithful three-term bf16 products'),
+    # BASELINE configs[4]: CIFAR-10-shaped LeNet, 256 particles over 8 GPUs = 32 per GPU, bf16; 4000 training images as
+    # experiments/mclmc_cifar_lenet_b5.yaml (5000 synthetic images, 0.8 train split)
+    'B5': dict(ensemble=32, kernel='lenet_bf16', dtype='bf16', peak=PEAK_BF16_MFMA_TFLOPS, steps=20, warmup=3, cpu_particles=1, cpu_seconds=8.0,
+               model='lenet', image=(3, 32, 32), classes=10, rows=4000,
+               text='B5: CIFAR-10-shaped N=4000 images 3x32x32, LeNet (conv 6@5x5 pad 2, pool, conv 16@5x5, pool, 120, 84, 10) relu, '
+                    'softmax head, StandardNormal prior, d=83126, 32 particles per GPU (of 256 over 8); convolution products as '
+                    'implicit GEMMs on bf16 MFMA (bf16 operands, fp32 accumulation), Dense layers / integrator fp32'),
 }
+# bounded secondary legs of the default run: (workload, steps per repetition, warm-up steps)
+SECONDARY = (('B3', 10, 3), ('B4', 2, 1), ('B5', 10, 2))
 
 
 def grad_flops_per_particle(F, hs, N):
@@ -71,7 +80,15 @@ def grad_flops_per_particle(F, hs, N):
     return 2 * N * W + 4 * N * W - 2 * N * W0
 
 
-def cpu_baseline(spec_o, prob, oracle, seconds_target=15.0):
+def lenet_grad_flops_per_particle(C, H, W, K, N):
+    """Algorithmic FLOPs of one LeNet gradient evaluation: forward 2 N M, backward 4 N M minus the first layer's input gradient."""
+    h2, w2 = H // 2 - 4, W // 2 - 4
+    m1 = H * W * 25 * C * 6
+    m = m1 + h2 * w2 * 150 * 16 + (h2 // 2) * (w2 // 2) * 16 * 120 + 120 * 84 + 84 * K
+    return (6 * m - 2 * m1) * N
+
+
+def cpu_baseline(spec_o, prob, oracle, seconds_target=15.0, logpost_and_grad=None):
     """The oracle's C/OpenMP restatement (oracle/cpu_mclmc.c: fp32, one particle per core, the shape
     of the reference's own CPU run) on the host cores, on a bounded sample of the same workload: all E
     particles, a few steps.  Falls back to the NumPy oracle if the C library cannot be built."""
@@ -80,6 +97,8 @@ def cpu_baseline(spec_o, prob, oracle, seconds_target=15.0):
     E, d = prob['theta0'].shape
     rng = np.random.default_rng(0)
     try:
+        if logpost_and_grad is not None:
+            raise NotImplementedError('the C port restates the FCN only')
         from oracle.cpu_c import CpuPort
         port = CpuPort(spec_o, prob['X'], prob['y'])
         x = prob['theta0'].astype(dt).copy()
@@ -105,7 +124,8 @@ def cpu_baseline(spec_o, prob, oracle, seconds_target=15.0):
         cores = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
     except Exception:
         cores = os.cpu_count() or 1
-    f = lambda th: oracle.logpost_and_grad(spec_o, th, prob['X'], prob['y'])
+    lg = logpost_and_grad or oracle.logpost_and_grad
+    f = lambda th: lg(spec_o, th, prob['X'], prob['y'])
     st = oracle.mclmc_init(f, prob['theta0'].astype(dt), prob['u0'].astype(dt))
     eps, L = prob['eps'].astype(dt), prob['L'].astype(dt)
     n, t0 = 0, time.perf_counter()
@@ -172,13 +192,25 @@ class Leg:
         self.torch, self.oracle, self.dist, self.rank, self.world, self.dev = torch, oracle, dist, rank, world, dev
         self.name, self.wl = name, WORKLOADS[name]
         self.gather_cpu, self.async_gather = gather_cpu, args.async_gather
-        self.spec_o, self.N, _ = oracle.config_spec(name)
         self.E = E = args.ensemble if (args.ensemble and name == args.workload) else self.wl['ensemble']
         kernel = args.grad_kernel if (args.grad_kernel and name == args.workload) else self.wl['kernel']
-        self.prob = prob = oracle.synthetic_problem(self.spec_o, self.N, E * world, seed=0)
+        self.lenet = self.wl.get('model') == 'lenet'
+        if self.lenet:
+            from oracle import lenet_oracle
+            from mile_amd import LeNetSpec
+            (C, H, W), K = self.wl['image'], self.wl['classes']
+            self.lenet_oracle = lenet_oracle
+            self.spec_o, self.N = lenet_oracle.LeNetSpec(C, H, W, K), self.wl['rows']
+            self.prob = prob = lenet_oracle.synthetic_problem(self.spec_o, self.N, E * world, seed=0)
+            self.spec = LeNetSpec(C, H, W, K)
+            self.flops_per_particle = lenet_grad_flops_per_particle(C, H, W, K, self.N)
+        else:
+            self.spec_o, self.N, _ = oracle.config_spec(name)
+            self.prob = prob = oracle.synthetic_problem(self.spec_o, self.N, E * world, seed=0)
+            self.spec = ModelSpec(self.spec_o.in_features, self.spec_o.hidden_structure, activation='relu', task=self.spec_o.task,
+                                  prior='StandardNormal')
+            self.flops_per_particle = grad_flops_per_particle(self.spec.in_features, self.spec.hidden_structure, self.N)
         lo, hi = rank * E, (rank + 1) * E
-        self.spec = ModelSpec(self.spec_o.in_features, self.spec_o.hidden_structure, activation='relu', task=self.spec_o.task,
-                              prior='StandardNormal')
         self.eng = Engine(self.spec, torch.from_numpy(prob['X']), torch.from_numpy(prob['y']), device=dev, grad_kernel=kernel)
         self.ids = torch.arange(lo, hi, dtype=torch.int32, device=dev)
         self.eps = torch.from_numpy(prob['eps'][lo:hi]).to(dev)
@@ -260,7 +292,7 @@ class Leg:
         self.run(k_steps, IntegratorState(*(t.clone() for t in self.state)), collect=False)
         self.torch.cuda.synchronize()
         ms, n_launch = eng.grad_timing_end()
-        flops = grad_flops_per_particle(spec.in_features, spec.hidden_structure, self.N) * E
+        flops = self.flops_per_particle * E
         avg_s = ms * 1e-3 / max(n_launch, 1)
         achieved = flops / avg_s / 1e12
         info = eng.grad_launch_info(E)
@@ -270,12 +302,16 @@ class Leg:
             if tj.exists() and self.name == 'B2' and E == WORKLOADS['B2']['ensemble'] and info['kernel'] == 'k_grad_w64':
                 traffic = json.loads(tj.read_text())['hbm_bytes_per_launch']
                 break
-        peak = self.wl['peak'] if eng.grad_kernel == 'mfma_w128_bf16' or self.name in ('B2', 'B4') else PEAK_FP32_MFMA_TFLOPS
+        peak = self.wl['peak'] if eng.grad_kernel in ('mfma_w128_bf16', 'lenet_bf16') or self.name in ('B2', 'B4') else PEAK_FP32_MFMA_TFLOPS
         roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak,
                 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic,
                 'kernel': info['kernel'], 'grid': list(info['grid']), 'lds_bytes': info['lds_bytes'],
                 'avg_launch_us': round(avg_s * 1e6, 2), 'launches_timed': n_launch,
                 'flop_per_launch': flops}
+        if self.lenet:
+            roof['kernel_note'] = ('avg_launch_us is one whole gradient: five convolution launches (the MFMA share), pooling fused, three Dense '
+                                   'layers as rocBLAS SGEMMs, head; priced against the bf16 dense peak although only the convolution products '
+                                   'run on it')
         if eng.grad_kernel == 'mfma_wide_bf16x3':
             # every product is six bf16 MFMA products (32 clk per 16-deep chunk) instead of eight fp32 MFMAs of 64 clk
             roof['mix'] = 'all Dense products as 6 bf16 MFMA products of exact 3-term bf16 splits (fp32-faithful), layer-wise GEMMs'
@@ -297,10 +333,12 @@ class Leg:
     def cpu(self):
         Ec = self.E if self.wl['cpu_particles'] is None else min(self.E, self.wl['cpu_particles'])   # bounded sample
         prob1 = {k: (v[:Ec] if k in ('theta0', 'u0', 'eps', 'L') else v) for k, v in self.prob.items()}
+        if self.lenet:      # NumPy oracle of the same recipe (no C port for the convolutions)
+            return cpu_baseline(self.spec_o, prob1, self.oracle, self.wl['cpu_seconds'], logpost_and_grad=self.lenet_oracle.logpost_and_grad_bf16)
         return cpu_baseline(self.spec_o, prob1, self.oracle, self.wl['cpu_seconds'])
 
     def dtype(self):
-        return self.wl['dtype'] if self.eng.grad_kernel == 'mfma_w128_bf16' or self.name in ('B2', 'B4') else 'f32'
+        return self.wl['dtype'] if self.eng.grad_kernel in ('mfma_w128_bf16', 'lenet_bf16') or self.name in ('B2', 'B4') else 'f32'
 
 
 def main():
@@ -313,7 +351,7 @@ def main():
     ap.add_argument('--grad-kernel', default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--no-secondary', action='store_true', help='skip the bounded B3 leg of the default run')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the bounded B3 / B4 / B5 legs of the default run')
     ap.add_argument('--async-gather', action='store_true',
                     help='N > 1: overlap each chunk\'s RCCL all-gather with the next chunk (default: ordered on the compute stream)')
     ap.add_argument('--force-dist', action='store_true', help='init the process group even for 1 rank (rehearsal)')
@@ -380,20 +418,21 @@ def main():
 
     secondary = None
     if world == 1 and args.workload == 'B2' and not args.no_secondary and args.ensemble is None and args.grad_kernel is None:
-        # BASELINE configs[2] (B3), bounded: ~10 steps per repetition, 16 particles on the CPU side
-        name = 'B3'
-        leg2 = Leg(name, args, None, 0, 1, dev, gather_cpu=False)
-        k2 = 10
-        tm2 = leg2.measure(k2, 3, budget_s=0.5, min_reps=3, max_reps=5)
-        sec = {'metric': 'MCLMC integrator particle-steps/s', 'value': round(leg2.E * k2 / tm2['median'], 1),
-               'unit': 'particle-steps/s', 'ms_per_step': round(tm2['median'] / k2 * 1e3, 4), 'steps': k2, 'reps': tm2['reps'],
-               'dtype': leg2.dtype(), 'config': {'workload': leg2.wl['text'], 'ensemble_per_gpu': leg2.E,
-                                                 'grad_kernel': leg2.eng.grad_kernel,
-                                                 'finite': bool(torch.isfinite(leg2.state.position).all().item())},
-               'roofline': None if args.no_kernel_timing else leg2.roofline(k2, args),
-               'cpu_baseline': None if args.no_cpu_baseline else leg2.cpu()}
-        secondary = {name: sec}
-        del leg2
+        # BASELINE configs[2..4] (B3, B4 per GPU, B5 per GPU), bounded: a few steps per repetition, 1-16 particles on the CPU side
+        secondary = {}
+        for name, k2, w2 in SECONDARY:
+            leg2 = Leg(name, args, None, 0, 1, dev, gather_cpu=False)
+            tm2 = leg2.measure(k2, w2, budget_s=0.5, min_reps=3, max_reps=5)
+            secondary[name] = {
+                'metric': 'MCLMC integrator particle-steps/s', 'value': round(leg2.E * k2 / tm2['median'], 1),
+                'unit': 'particle-steps/s', 'ms_per_step': round(tm2['median'] / k2 * 1e3, 4), 'steps': k2, 'reps': tm2['reps'],
+                'dtype': leg2.dtype(), 'config': {'workload': leg2.wl['text'], 'ensemble_per_gpu': leg2.E,
+                                                  'grad_kernel': leg2.eng.grad_kernel,
+                                                  'finite': bool(torch.isfinite(leg2.state.position).all().item())},
+                'roofline': None if args.no_kernel_timing else leg2.roofline(k2, args),
+                'cpu_baseline': None if args.no_cpu_baseline else leg2.cpu()}
+            del leg2
+            torch.cuda.empty_cache()
 
     if rank == 0:
         cpu = None if args.no_cpu_baseline else leg.cpu()
