@@ -907,13 +907,19 @@ static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t s
 #ifndef MILE_MM_KC
 #define MILE_MM_KC 32     // K chunk of k_mm3: 32 = two workgroups per CU (mile_mm3.h); 64 = one, measured slower
 #endif
-template <int ALAY, int BSRC, int EPI, int TERMS, int ACT, bool ACCUM, bool COLSUM>
+template <int ALAY, int BSRC, int EPI, int TERMS, int ACT, bool ACCUM, bool COLSUM, bool FULL = false>
 static hipError_t launch_mm3_k(const MMParams &p, int batch, hipStream_t st) {
   constexpr int KC = MILE_MM_KC;
   using LY = MMLayout<ALAY, BSRC, TERMS, KC>;
+  static const bool dbg = getenv("MILE_DEBUG") && (atoi(getenv("MILE_DEBUG")) & 64);
+  if constexpr (!FULL) {   // whole tiles everywhere: the predicate-free instantiation (timing stamps need the general one)
+    static const bool no_full = getenv("MILE_MM_NO_FULL") != nullptr;
+    if (!dbg && !no_full && p.M % 128 == 0 && p.N % 128 == 0 && p.K % KC == 0)
+      return launch_mm3_k<ALAY, BSRC, EPI, TERMS, ACT, ACCUM, COLSUM, true>(p, batch, st);
+  }
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_mm3<ALAY, BSRC, EPI, TERMS, KC, ACT, ACCUM, COLSUM>,
+    hipError_t e = hipFuncSetAttribute((const void *)k_mm3<ALAY, BSRC, EPI, TERMS, KC, ACT, ACCUM, COLSUM, FULL>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LY::BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
@@ -928,14 +934,13 @@ static hipError_t launch_mm3_k(const MMParams &p, int batch, hipStream_t st) {
     if (COLSUM && batch % 8 == 0) q.xcd_remap = 2;                     // dW: the few tiles of a particle share both operands
     else if (!COLSUM && grid.x > 1 && grid.y >= 8) q.xcd_remap = 1;
   }
-  static const bool dbg = getenv("MILE_DEBUG") && (atoi(getenv("MILE_DEBUG")) & 64);
   static unsigned long long *dbuf = nullptr;
   if (dbg) {   // dev: mean time per phase of wave 0 (100 MHz ticks -> us), per launch
     if (!dbuf && hipMalloc(&dbuf, 64) != hipSuccess) return hipErrorOutOfMemory;
     (void)hipMemsetAsync(dbuf, 0, 64, st);
     q.dbg = dbuf;
   }
-  k_mm3<ALAY, BSRC, EPI, TERMS, KC, ACT, ACCUM, COLSUM><<<grid, 256, LY::BYTES, st>>>(q);
+  k_mm3<ALAY, BSRC, EPI, TERMS, KC, ACT, ACCUM, COLSUM, FULL><<<grid, 256, LY::BYTES, st>>>(q);
   if (dbg) {
     unsigned long long h[8];
     (void)hipStreamSynchronize(st);

@@ -126,7 +126,10 @@ struct MMLayout {
 // ACT (MILE_ACT_* or -1 = none) and ACCUM are template parameters: the epilogue's 64 elements per lane run branch-free
 // (as a per-element run-time switch the epilogue was most of the kernel's instructions; dispatched inside the kernel its
 // eight inlined copies spilled 150 registers).
-template <int ALAY, int BSRC, int EPI, int TERMS, int KC, int ACT, bool ACCUM, bool COLSUM = false>
+// FULL: M and N are multiples of 128 and K of KC (the hidden layers of B4 at every chunk size the host picks): no tile / row /
+// column / ragged-chunk predicates and no timing stamps -- the K loop is one basic block the scheduler can order freely
+// (the general form carries ~3 SALU instructions per MFMA and a branch around every MFMA group).
+template <int ALAY, int BSRC, int EPI, int TERMS, int KC, int ACT, bool ACCUM, bool COLSUM = false, bool FULL = false>
 __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
   using LY = MMLayout<ALAY, BSRC, TERMS, KC>;
   static_assert(KC == 32 || KC == 64, "K chunk");
@@ -230,16 +233,16 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
 #pragma unroll
     for (int i = 0; i < A_NP; ++i) {
       const int m = m0 + r0 + (256 / A_TPR) * i;
-      voa[i] = m < M ? (m * p.lda + 4 * c4) * 4 : MM_OOB;
+      voa[i] = (FULL || m < M) ? (m * p.lda + 4 * c4) * 4 : MM_OOB;
     }
   } else {
     const int c4 = tid & 31, r0 = tid >> 5;
 #pragma unroll
-    for (int i = 0; i < A_NP; ++i) voa[i] = m0 + 4 * c4 < M ? ((r0 + 8 * i) * p.lda + m0 + 4 * c4) * 4 : MM_OOB;
+    for (int i = 0; i < A_NP; ++i) voa[i] = (FULL || m0 + 4 * c4 < M) ? ((r0 + 8 * i) * p.lda + m0 + 4 * c4) * 4 : MM_OOB;
   }
   auto load_a = [&](const int st, const int k0) {
     const int so = ALAY == MM_A_MK ? k0 * 4 : k0 * p.lda * 4;
-    const bool ragged = k0 + KC > K;
+    const bool ragged = !FULL && k0 + KC > K;
 #pragma unroll
     for (int i = 0; i < A_NP; ++i) {
       int vo = voa[i];
@@ -289,21 +292,21 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
   if constexpr (BSRC == MM_B_F32_KN) {
     const int c4 = tid & 31, r0 = tid >> 5;
 #pragma unroll
-    for (int i = 0; i < B_NP; ++i) vob[i] = n0 + 4 * c4 < N ? ((r0 + 8 * i) * p.ldb + n0 + 4 * c4) * 4 : MM_OOB;
+    for (int i = 0; i < B_NP; ++i) vob[i] = (FULL || n0 + 4 * c4 < N) ? ((r0 + 8 * i) * p.ldb + n0 + 4 * c4) * 4 : MM_OOB;
   } else if constexpr (BSRC == MM_B_T3_KN) {
     const int c = tid & 15, r0 = tid >> 4;            // [KC k][128 n]: 16 chunks of 8 columns per row
 #pragma unroll
-    for (int i = 0; i < B_NP; ++i) vob[i] = n0 + 8 * c < N ? ((r0 + 16 * i) * p.ldb + n0 + 8 * c) * 2 : MM_OOB;
+    for (int i = 0; i < B_NP; ++i) vob[i] = (FULL || n0 + 8 * c < N) ? ((r0 + 16 * i) * p.ldb + n0 + 8 * c) * 2 : MM_OOB;
   } else {
     const int c = tid % NK_CPR, r0 = tid / NK_CPR;    // [128 n][KC k]: KC / 8 chunks of 8 k per row
 #pragma unroll
     for (int i = 0; i < B_NP; ++i) {
       const int n = n0 + r0 + (256 / NK_CPR) * i;
-      vob[i] = n < N ? (n * p.ldb + 8 * c) * 2 : MM_OOB;
+      vob[i] = (FULL || n < N) ? (n * p.ldb + 8 * c) * 2 : MM_OOB;
     }
   }
   auto load_b = [&](const int st, const int k0) {
-    const bool ragged = k0 + KC > K;
+    const bool ragged = !FULL && k0 + KC > K;
     if constexpr (BSRC == MM_B_F32_KN) {
       const int so = k0 * p.ldb * 4;
 #pragma unroll
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
   // 32 x 32 tiles of this wave that lie inside the matrix (skinny products skip the MFMAs of the rest; wave-uniform)
   bool mt_on[2], nt_on[2];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) nt_on[q] = n0 + 64 * wn + 32 * q < N;
+  for (int q = 0; q < 2; ++q) nt_on[q] = FULL || n0 + 64 * wn + 32 * q < N;
 
   // ---- epilogue of one C tile: D[m = acc_m(reg, h)][n = r] per 32 x 32 MFMA tile ---------------------------------------
   // The wave's 64 x 64 quadrant goes through LDS in two 32-row halves ([32][68] floats = 8.7 KB per wave, aliasing the operand
@@ -395,9 +398,9 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
     if constexpr (EPI == MM_EPI_BIAS_ACT) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        if (nq + c < N) bias4[c] = p.bias[(size_t)bz * p.sBias + nq + c];
+        if (FULL || nq + c < N) bias4[c] = p.bias[(size_t)bz * p.sBias + nq + c];
     }
-    const bool vec_ok = nq + 3 < N && p.c_vec;                  // whole float4 inside the matrix and 16-byte aligned
+    const bool vec_ok = (FULL || nq + 3 < N) && p.c_vec;                  // whole float4 inside the matrix and 16-byte aligned
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       if (!mt_on[a]) continue;                                  // wave-uniform
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int m = mr0 + rr + 4 * i;
-          hv[i] = (m < M && nq < N) ? *(const f32x4 *)(p.Hprev + (size_t)bz * p.sH + (size_t)m * p.ldh + nq)
+          hv[i] = (FULL || (m < M && nq < N)) ? *(const f32x4 *)(p.Hprev + (size_t)bz * p.sH + (size_t)m * p.ldh + nq)
                                                          : f32x4{1.0f, 1.0f, 1.0f, 1.0f};
         }
       }
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
           const int m = mr0 + rr + 4 * i;
           const float *c = C + (size_t)m * p.ldc + nq;
           cv[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-          if (m < M) {
+          if (FULL || m < M) {
             if (vec_ok) cv[i] = *(const f32x4 *)c;
             else {
 #pragma unroll
@@ -452,7 +455,7 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
           if constexpr (ACCUM) x += cv[i][cc];
           v[cc] = x;
         }
-        if (m < M) {
+        if (FULL || m < M) {
           float *c = C + (size_t)m * p.ldc + nq;
           if (vec_ok) *(f32x4 *)c = v;
           else {
@@ -476,14 +479,14 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
       load_b(j, KC * j);
     }
 #pragma unroll
-  for (int q = 0; q < 2; ++q) mt_on[q] = m0 + 64 * wm + 32 * q < M;
+  for (int q = 0; q < 2; ++q) mt_on[q] = FULL || m0 + 64 * wm + 32 * q < M;
   for (int g0 = 0; g0 < nk; g0 += PF)
 #pragma unroll
   for (int j = 0; j < PF; ++j) {
     const int kc = g0 + j;
     if (kc >= nk) break;
     long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
-    const bool stampw = p.dbg != nullptr && tid == 0;
+    const bool stampw = !FULL && p.dbg != nullptr && tid == 0;
     if (stampw) ts0 = wall_clock64();
     __syncthreads();          // every wave has read the previous chunk's images
     if (stampw) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ts1 = wall_clock64(); }
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
       load_a(j, KC * (kc + PF));
       load_b(j, KC * (kc + PF));
     }
-    const int ksteps = min(KC / 16, (K - KC * kc + 15) / 16);
+    const int ksteps = FULL ? KC / 16 : min(KC / 16, (K - KC * kc + 15) / 16);
     auto kstep = [&](const int ks) {
       bf16x8 af[2][TERMS], bfr[2][TERMS];
 #pragma unroll
@@ -540,7 +543,7 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
     }
   }
   if constexpr (COLSUM) {
-    if (by == 0) {     // thread (c4, r0) holds columns n0 + 4 c4 .. + 3 summed over its k rows: add the 8 row groups
+    if (by == 0) {     // (FULL changes nothing here) thread (c4, r0) holds columns n0 + 4 c4 .. + 3 summed over its k rows: add the 8 row groups
       __syncthreads();
       float *red = reinterpret_cast<float *>(mm_smem);                    // [8][128]
       const int c4 = tid & 31, r0 = tid >> 5;
