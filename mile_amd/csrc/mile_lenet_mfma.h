@@ -43,7 +43,7 @@ __device__ __forceinline__ int cm_div(int p, float inv) { return (int)(((float)p
 
 // Slot geometry.  PB = bytes per pixel of the tile; off(s, rowpix) = byte offset of slot s from the pixel base (rowpix =
 // pixels per tile row); tap(s) / c0(s) = kernel tap and first channel the slot stands for; NS slots in all.
-enum { CM_IN4 = 0, CM_IN8 = 1, CM_DZ16 = 2 };
+enum { CM_IN4 = 0, CM_IN8 = 1, CM_DZ16 = 2, CM_DZ16P = 3 };
 template <int MODE> struct CSlot;
 template <> struct CSlot<CM_IN4> {   // <= 4 input channels: slot = (kh, kw) with kw padded to 6 (kw = 5 is a zero tap)
   static constexpr int NS = 30, PB = 8;
@@ -64,6 +64,14 @@ template <> struct CSlot<CM_DZ16> {  // the dZ tile of the input-gradient pass, 
   __device__ static int off(int s, int rowpix) { return -(((s >> 2) / 5) * rowpix + (s >> 2) % 5) * 32 + 8 * (s & 3); }
   __device__ static bool valid(int s) { return s < NS; }
   __device__ static int tap(int s) { return s >> 2; }
+  __device__ static int c0(int s) { return 4 * (s & 3); }
+};
+
+template <> struct CSlot<CM_DZ16P> { // dZ tile, pair form: slot = (kh, kw' = -1..4, quarter)
+  static constexpr int NS = 120, PB = 32;
+  __device__ static int off(int s, int rowpix) { return -((s / 24) * rowpix + ((s % 24) >> 2) - 1) * 32 + 8 * (s & 3); }
+  __device__ static bool valid(int s) { return s < NS; }
+  __device__ static int tap(int) { return 0; }     // unused: the pair forms index the kernel themselves
   __device__ static int c0(int s) { return 4 * (s & 3); }
 };
 
@@ -116,7 +124,13 @@ __device__ __forceinline__ void cm_stage_input(char *tile, const float *src, lon
 // K is read through an LDS copy (Ksh, 25 * CIN * COUT floats, aliasing the image tile): the gather below is 8 NMF scalar reads per
 // lane, which as global loads cost the workgroup more than the images it then processes.  Ends with a barrier-free state: the
 // caller's image loop starts with __syncthreads() before it overwrites the tile.
-template <int MODE, int NMF, bool DX>
+// KIND: CK_FWD rows = output channels; CK_DX rows = input channels; CK_FWD2 / CK_DX2 the PAIR forms: row m = 2 * channel + dxo
+// stands for the output pixel x + dxo of a pixel PAIR (x even), i.e. the kernel shifted by dxo inside a 6-wide kw window:
+//   out[x + dxo][co]  = sum_{kw'} in[x + kw'] K[kw' - dxo][co]            (kw' = 0..5, the padded slots of CM_IN4)
+//   din[x + dxo][ci]  = sum_{kw'} dz[x - kw'] K[kw' + dxo][ci]            (kw' = -1..4, CM_DZ16P)
+// -- twice the useful MFMA rows (12 of 16 instead of 6) and half the tiles for the 6-channel sides of the two convolutions.
+enum { CK_FWD = 0, CK_DX = 1, CK_FWD2 = 2, CK_DX2 = 3 };
+template <int MODE, int NMF, int KIND>
 __device__ __forceinline__ void cm_kernel_operand(const float *Kg, float *K, int CIN, int COUT, int tid, bf16x8 (&ka)[NMF]) {
   using G = CSlot<MODE>;
   for (int i = tid; i < 25 * CIN * COUT; i += 256) K[i] = Kg[i];
@@ -129,10 +143,19 @@ __device__ __forceinline__ void cm_kernel_operand(const float *Kg, float *K, int
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int s = 2 * (4 * c + g) + (j >> 2), ch = G::c0(s) + (j & 3);
-      bool ok = G::valid(s);
+      bool ok;
       int idx;
-      if constexpr (DX) { ok = ok && m < CIN && ch < COUT; idx = (G::tap(s) * CIN + m) * COUT + ch; }
-      else { ok = ok && ch < CIN && m < COUT; idx = (G::tap(s) * CIN + ch) * COUT + m; }
+      if constexpr (KIND == CK_DX) { ok = G::valid(s) && m < CIN && ch < COUT; idx = (G::tap(s) * CIN + m) * COUT + ch; }
+      else if constexpr (KIND == CK_FWD) { ok = G::valid(s) && ch < CIN && m < COUT; idx = (G::tap(s) * CIN + ch) * COUT + m; }
+      else if constexpr (KIND == CK_FWD2) {   // CM_IN4 slots: s = 6 kh + kw'
+        const int kh = s / 6, kw = s % 6 - (m & 1), co = m >> 1;
+        ok = s < G::NS && kw >= 0 && kw < 5 && ch < CIN && co < COUT;
+        idx = ((kh * 5 + kw) * CIN + ch) * COUT + co;
+      } else {                                // CM_DZ16P slots: s = 24 kh + 4 (kw' + 1) + quarter
+        const int kh = s / 24, kw = ((s % 24) >> 2) - 1 + (m & 1), ci = m >> 1;
+        ok = s < G::NS && kw >= 0 && kw < 5 && ci < CIN && ch < COUT;
+        idx = ((kh * 5 + kw) * CIN + ci) * COUT + ch;
+      }
       v[j] = ok ? K[idx] : 0.0f;
     }
     const cm_u32x4 pk = {cm_pack2(v[0], v[1]), cm_pack2(v[2], v[3]), cm_pack2(v[4], v[5]), cm_pack2(v[6], v[7])};
@@ -222,7 +245,7 @@ __global__ __launch_bounds__(256) void k_conv5m_fwd(const float *in, long long s
   const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4, Wp = W + 2 * pad, npix = Ho * Wo;
   const int Hq = Ho / 2, Wq = Wo / 2, TX = (Wo + 7) / 8, ntiles = ((Ho + 1) / 2) * TX;
   bf16x8 ka[NMF];
-  cm_kernel_operand<MODE, NMF, false>(theta + (size_t)e * d + k_off, reinterpret_cast<float *>(cm_lds), CIN, COUT, tid, ka);
+  cm_kernel_operand<MODE, NMF, CK_FWD>(theta + (size_t)e * d + k_off, reinterpret_cast<float *>(cm_lds), CIN, COUT, tid, ka);
   int so[NMF][2];
 #pragma unroll
   for (int c = 0; c < NMF; ++c)
@@ -286,6 +309,67 @@ __global__ __launch_bounds__(256) void k_conv5m_fwd(const float *in, long long s
   }
 }
 
+// The forward convolution in the PAIR form (CK_FWD2; <= 4 input channels, 2 COUT <= 16): an MFMA column is the pixel pair
+// (y, x), (y, x + 1) with x even, rows are (output channel, which pixel of the pair).  A tile = 2 rows x 8 pairs = 2 x 16 pixels:
+// the horizontal half of a pooling window sits in ONE lane (registers i, i + 1), the vertical half in lane n ^ 8.
+template <int COUT>
+__global__ __launch_bounds__(256) void k_conv5m_fwd2x(const float *in, long long sE, long long sB, long long sH, long long sW, long long sC,
+                                                      int CIN, int H, int W, int pad, const float *theta, int k_off, int b_off, int d, float *out,
+                                                      float *pool, int R, int ipw, int activation) {
+  using G = CSlot<CM_IN4>;
+  static_assert(2 * COUT <= 16 && COUT % 2 == 0, "rows = (channel, pixel of the pair)");
+  constexpr int NMF = ((G::NS + 1) / 2 + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) char cm_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e = blockIdx.y;
+  const int n16 = lane & 15, g = lane >> 4;
+  const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4, Wp = W + 2 * pad, npix = Ho * Wo;
+  const int Hq = Ho / 2, Wq = Wo / 2, TX = (Wo + 15) / 16, ntiles = ((Ho + 1) / 2) * TX;
+  bf16x8 ka[NMF];
+  cm_kernel_operand<CM_IN4, NMF, CK_FWD2>(theta + (size_t)e * d + k_off, reinterpret_cast<float *>(cm_lds), CIN, COUT, tid, ka);
+  int so[NMF][2];
+#pragma unroll
+  for (int c = 0; c < NMF; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int s = 2 * (4 * c + g) + u;
+      so[c][u] = s < G::NS ? G::off(s, Wp) : 0;
+    }
+  const bool rows_on = 2 * g < COUT;                 // this lane's rows are channels 2 g, 2 g + 1
+  const float bias0 = rows_on ? theta[(size_t)e * d + b_off + 2 * g] : 0.0f, bias1 = rows_on ? theta[(size_t)e * d + b_off + 2 * g + 1] : 0.0f;
+  const float inv_tx = 1.0f / (float)TX;
+  const int dy = n16 >> 3, px = n16 & 7;
+  const int b0 = blockIdx.x * ipw, b1 = min(R, b0 + ipw);
+  for (int b = b0; b < b1; ++b) {
+    __syncthreads();
+    cm_stage_input<CM_IN4>(cm_lds, in + (size_t)e * sE + (size_t)b * sB, sH, sW, sC, CIN, H, W, pad, tid);
+    __syncthreads();
+    float *dst = out ? out + ((size_t)e * R + b) * npix * COUT : nullptr;
+    float *pdst = pool + ((size_t)e * R + b) * Hq * Wq * COUT;
+    cm_image_f<NMF>(cm_lds, ntiles, wave, so, ka,
+      [&](const int t) {
+        const int ty = cm_div(t, inv_tx), tx = t - ty * TX;
+        const int y = min(2 * ty + dy, Ho - 1), x = min(16 * tx + 2 * px, Wo - 1);
+        return (y * Wp + x) * G::PB;
+      },
+      [&](const int t, const cm_f32x4 acc) {
+        const int ty = cm_div(t, inv_tx), tx = t - ty * TX;
+        const int y = 2 * ty + dy, x = 16 * tx + 2 * px;
+        // registers: 0 = (channel 2g, x), 1 = (2g, x + 1), 2 = (2g + 1, x), 3 = (2g + 1, x + 1)
+        const float v0 = act_fwd(activation, acc[0] + bias0), v1 = act_fwd(activation, acc[1] + bias0);
+        const float v2 = act_fwd(activation, acc[2] + bias1), v3 = act_fwd(activation, acc[3] + bias1);
+        if (dst && rows_on && y < Ho) {
+          float *o = dst + (size_t)(y * Wo + x) * COUT + 2 * g;
+          if (x < Wo) *reinterpret_cast<cm_f32x2 *>(o) = cm_f32x2{v0, v2};
+          if (x + 1 < Wo) *reinterpret_cast<cm_f32x2 *>(o + COUT) = cm_f32x2{v1, v3};
+        }
+        const float h0 = v0 + v1, h1 = v2 + v3;        // window sum in the order of k_avgpool2: (a00 + a01) + (a10 + a11)
+        const float s0 = 0.25f * (h0 + __shfl_xor(h0, 8)), s1 = 0.25f * (h1 + __shfl_xor(h1, 8));
+        if (rows_on && dy == 0 && y < 2 * Hq && x < 2 * Wq)
+          *reinterpret_cast<cm_f32x2 *>(pdst + (size_t)((y >> 1) * Wq + (x >> 1)) * COUT + 2 * g) = cm_f32x2{s0, s1};
+      });
+  }
+}
+
 // bf16 dZ tile of one image with a zero halo: tile[(y + HALO) * Wt + x + HALO][16 channels], Wt = Wo + 2 HALO;
 // dz = unpool(dp) * act'(a): dz[y][x][c] = (avg-pool backward: dp[y/2][x/2][c] / 4, zero on the cropped border) * act'(a[y][x][c])
 // (mile_lenet.h dz_from_pool).  npix_alloc pixels are written (zeros outside the image).  One pixel per thread and pass, its
@@ -294,7 +378,7 @@ template <int COUT>
 __device__ __forceinline__ void cm_stage_dz(char *zt, const float *dp_img, const float *a_img, int Ho, int Wo, int halo, int npix_alloc,
                                             int activation, int tid) {
   static_assert(COUT % 2 == 0 && COUT <= 16, "channel pairs");
-  constexpr int U = 4, VW = COUT % 4 == 0 ? 4 : 2;
+  constexpr int U = COUT > 8 ? 2 : 4, VW = COUT % 4 == 0 ? 4 : 2;   // 2 x 16 channels x (a, dp) = 64 registers in flight
   const int Wt = Wo + 2 * halo, Ht = Ho + 2 * halo, Hq = Ho / 2, Wq = Wo / 2;
   const float inv_wt = 1.0f / (float)Wt;
   for (int i0 = tid; i0 < npix_alloc; i0 += 256 * U) {
@@ -355,7 +439,7 @@ __global__ __launch_bounds__(256) void k_conv5m_dx(const float *dp, const float 
   const int n16 = lane & 15, g = lane >> 4;
   const int H = Ho + 4, W = Wo + 4, Ht = Ho + 8, Wt = Wo + 8, npix = H * W;
   bf16x8 ka[NMF];
-  cm_kernel_operand<CM_DZ16, NMF, true>(theta + (size_t)e * d + k_off, reinterpret_cast<float *>(cm_lds), CIN, COUT, tid, ka);
+  cm_kernel_operand<CM_DZ16, NMF, CK_DX>(theta + (size_t)e * d + k_off, reinterpret_cast<float *>(cm_lds), CIN, COUT, tid, ka);
   int so[NMF][2];
 #pragma unroll
   for (int c = 0; c < NMF; ++c)
@@ -385,6 +469,55 @@ __global__ __launch_bounds__(256) void k_conv5m_dx(const float *dp, const float 
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             if (4 * g + i < CIN) o[i] = acc[i];
+        }
+      });
+  }
+}
+
+// The input gradient in the PAIR form (CK_DX2, CM_DZ16P): an MFMA column is the input pixel pair (yi, xi), (yi, xi + 1), rows are
+// (input channel, which pixel): 12 of 16 rows useful for conv2's 6 input channels and 15 MFMAs per 32 pixels instead of 26.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void k_conv5m_dx2x(const float *dp, const float *a, int activation, const float *theta, int k_off, int d,
+                                                     float *din, int R, int Ho, int Wo, int ipw) {
+  using G = CSlot<CM_DZ16P>;
+  constexpr int NMF = ((G::NS + 1) / 2 + 3) / 4;
+  static_assert(COUT <= 16 && 2 * CIN <= 16 && CIN % 2 == 0, "one slot quartet / rows = (channel, pixel of the pair)");
+  extern __shared__ __attribute__((aligned(16))) char cm_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e = blockIdx.y;
+  const int n16 = lane & 15, g = lane >> 4;
+  const int H = Ho + 4, W = Wo + 4, Ht = Ho + 8, Wt = Wo + 8, npix = H * W, W2 = (W + 1) / 2, npairs = H * W2;
+  bf16x8 ka[NMF];
+  cm_kernel_operand<CM_DZ16P, NMF, CK_DX2>(theta + (size_t)e * d + k_off, reinterpret_cast<float *>(cm_lds), CIN, COUT, tid, ka);
+  int so[NMF][2];
+#pragma unroll
+  for (int c = 0; c < NMF; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int s = 2 * (4 * c + g) + u;
+      so[c][u] = s < G::NS ? G::off(s, Wt) : 0;
+    }
+  const float inv_w2 = 1.0f / (float)W2;
+  const int b0 = blockIdx.x * ipw, b1 = min(R, b0 + ipw);
+  for (int b = b0; b < b1; ++b) {
+    const size_t img = (size_t)e * R + b;
+    __syncthreads();
+    // + 8 pixels of zero slack: the kw' = -1 slot of an odd-width image's last pair reads one pixel past the tile
+    cm_stage_dz<COUT>(cm_lds, dp + img * (Ho / 2) * (Wo / 2) * COUT, a + img * Ho * Wo * COUT, Ho, Wo, 4, Ht * Wt + 8, activation, tid);
+    __syncthreads();
+    float *dst = din + img * npix * CIN;
+    cm_image_f<NMF>(cm_lds, (npairs + 15) / 16, wave, so, ka,
+      [&](const int t) {
+        const int pc = min(t * 16 + n16, npairs - 1);
+        const int yi = cm_div(pc, inv_w2), xi = 2 * (pc - yi * W2);
+        return ((yi + 4) * Wt + xi + 4) * 32;
+      },
+      [&](const int t, const cm_f32x4 acc) {
+        const int p = t * 16 + n16;
+        const int yi = cm_div(p, inv_w2), xi = 2 * (p - yi * W2);
+        if (p < npairs && 2 * g < CIN) {           // registers: 0 = (channel 2g, xi), 1 = (2g, xi + 1), 2 = (2g + 1, xi), 3 = (2g + 1, xi + 1)
+          float *o = dst + (size_t)(yi * W + xi) * CIN + 2 * g;
+          *reinterpret_cast<cm_f32x2 *>(o) = cm_f32x2{acc[0], acc[2]};
+          if (xi + 1 < W) *reinterpret_cast<cm_f32x2 *>(o + CIN) = cm_f32x2{acc[1], acc[3]};
         }
       });
   }
@@ -506,12 +639,190 @@ __global__ __launch_bounds__(256) void k_conv5m_dw(const float *in, long long sE
   }
 }
 
+// dZ of one image as PAIR rows for the kernel-gradient pass: zt[pair (y, x / 2)][column 2 co + dxo] = dz[y][x + dxo][co], bf16,
+// npairs_alloc rows written (zeros outside the image).  One pair per thread and pass, U pairs' loads in flight.
+template <int COUT>
+__device__ __forceinline__ void cm_stage_dz_pairs(char *zt, const float *dp_img, const float *a_img, int Ho, int Wo, int npairs_alloc,
+                                                  int activation, int tid) {
+  static_assert(COUT % 2 == 0 && 2 * COUT <= 16, "channel pairs, 16 columns");
+  constexpr int U = 2;
+  const int W2 = (Wo + 1) / 2, Hq = Ho / 2, Wq = Wo / 2;
+  const float inv_w2 = 1.0f / (float)W2;
+  for (int i0 = tid; i0 < npairs_alloc; i0 += 256 * U) {
+    float av[U][2][COUT], gv[U][2][COUT];
+    bool in[U][2];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int pi = i0 + 256 * u;
+      const int y = cm_div(pi, inv_w2), x = 2 * (pi - y * W2);
+#pragma unroll
+      for (int dxo = 0; dxo < 2; ++dxo) {
+        in[u][dxo] = pi < npairs_alloc && y < Ho && x + dxo < Wo;
+        const bool pin = in[u][dxo] && y < 2 * Hq && x + dxo < 2 * Wq;
+        const float *ap = a_img + (size_t)(in[u][dxo] ? y * Wo + x + dxo : 0) * COUT;
+        const float *gp = dp_img + (size_t)(pin ? (y >> 1) * Wq + ((x + dxo) >> 1) : 0) * COUT;
+#pragma unroll
+        for (int c = 0; c < COUT; c += 2) {
+          const cm_f32x2 ta = *reinterpret_cast<const cm_f32x2 *>(ap + c);
+          const cm_f32x2 tg = pin ? *reinterpret_cast<const cm_f32x2 *>(gp + c) : cm_f32x2{0.0f, 0.0f};
+          av[u][dxo][c] = ta[0]; av[u][dxo][c + 1] = ta[1]; gv[u][dxo][c] = tg[0]; gv[u][dxo][c + 1] = tg[1];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int pi = i0 + 256 * u;
+      if (pi >= npairs_alloc) continue;
+      uint32_t pk[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {          // packed word c = columns 2c, 2c + 1 = channel c at x and x + 1
+        float v0 = 0.0f, v1 = 0.0f;
+        if (c < COUT) {
+          v0 = in[u][0] ? 0.25f * gv[u][0][c] * act_bwd(activation, av[u][0][c]) : 0.0f;
+          v1 = in[u][1] ? 0.25f * gv[u][1][c] * act_bwd(activation, av[u][1][c]) : 0.0f;
+        }
+        pk[c] = cm_pack2(v0, v1);
+      }
+      *reinterpret_cast<cm_u32x4 *>(zt + (size_t)pi * 32) = cm_u32x4{pk[0], pk[1], pk[2], pk[3]};
+      *reinterpret_cast<cm_u32x4 *>(zt + (size_t)pi * 32 + 16) = cm_u32x4{pk[4], pk[5], pk[6], pk[7]};
+    }
+  }
+}
+
+// The kernel gradient in the PAIR form (<= 4 input channels, 2 COUT <= 16): the MFMA K index runs over pixel PAIRS, the B columns
+// are (output channel, which pixel of the pair):  D[(kh, kw', ci)][(co, dxo)] = sum_pairs in[y + kh][x + kw'][ci] dz[y][x + dxo][co]
+// is a contribution to dK[kh][kw' - dxo][ci][co], so dK[kh][kw] = D[kw][dxo = 0] + D[kw + 1][dxo = 1] -- half the MFMAs and
+// transposed reads of the pixel form, 12 of 16 columns useful instead of 6.  The two halves meet in the final LDS reduction.
+template <int COUT>
+__global__ __launch_bounds__(256) void k_conv5m_dw2x(const float *in, long long sE, long long sB, long long sH, long long sW, long long sC,
+                                                     int CIN, int H, int W, int pad, const float *dp, const float *a, int activation, float *part,
+                                                     int R, int ipw) {
+  using G = CSlot<CM_IN4>;
+  constexpr int NMT = (G::NS + 3) / 4;            // 8 accumulator tiles of 4 slots x 4 channels
+  static_assert(2 * COUT <= 16 && COUT % 2 == 0, "columns = (channel, pixel of the pair)");
+  extern __shared__ __attribute__((aligned(16))) char cm_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e = blockIdx.y;
+  const int g = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
+  const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4, Hp = H + 2 * pad, Wp = W + 2 * pad, npix = Ho * Wo;
+  const int W2 = (Wo + 1) / 2, npairs = Ho * W2, npairs32 = (npairs + 31) / 32 * 32;
+  char *tile = cm_lds;                                                  // (Hp * Wp + 8) pixels of 8 bytes
+  char *zt = cm_lds + ((size_t)(Hp * Wp + 8) * G::PB + 15) / 16 * 16;   // [npairs32][16] bf16
+  int so[NMT];
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt) so[mt] = 4 * mt + p4 < G::NS ? G::off(4 * mt + p4, Wp) : 0;
+  cm_f32x4 acc[NMT], accb = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt) acc[mt] = cm_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  const float inv_w2 = 1.0f / (float)W2;
+  const cm_u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
+  const int b0 = blockIdx.x * ipw, b1 = min(R, b0 + ipw);
+  for (int b = b0; b < b1; ++b) {
+    const size_t img = (size_t)e * R + b;
+    __syncthreads();
+    cm_stage_input<CM_IN4>(tile, in + (size_t)e * sE + (size_t)b * sB, sH, sW, sC, CIN, H, W, pad, tid);
+    cm_stage_dz_pairs<COUT>(zt, dp + img * (Ho / 2) * (Wo / 2) * COUT, a + img * npix * COUT, Ho, Wo, npairs32, activation, tid);
+    __syncthreads();
+    constexpr int NG = (NMT + 3) / 4;
+    static_assert(NG % 2 == 0, "the register double buffer returns to buffer 0 at every chunk");
+    bf16x4 a0[2][4], a1[2][4];
+    auto addr = [&](const int ch, int &bs0, int &bs1, int &zo0, int &zo1) {
+      const int P0 = 32 * ch + 8 * g + q, P1 = P0 + 4;            // this lane's two pair rows of the transposed reads
+      const int c0 = min(P0, npairs - 1), c1 = min(P1, npairs - 1);
+      const int y0 = cm_div(c0, inv_w2), x0 = 2 * (c0 - y0 * W2), y1 = cm_div(c1, inv_w2), x1 = 2 * (c1 - y1 * W2);
+      bs0 = (y0 * Wp + x0) * G::PB; bs1 = (y1 * Wp + x1) * G::PB;
+      zo0 = P0 * 32 + 8 * p4; zo1 = P1 * 32 + 8 * p4;
+    };
+    auto load_z = [&](const int zo0, const int zo1) {
+      const bf16x4 z0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, zt + zo0));
+      const bf16x4 z1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, zt + zo1));
+      return __builtin_shufflevector(z0, z1, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto load_a = [&](const int bs0, const int bs1, const int grp, bf16x4 (&f0)[4], bf16x4 (&f1)[4]) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int mt = 4 * grp + u;
+        if (mt < NMT) {
+          f0[u] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, tile + bs0 + so[mt]));
+          f1[u] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, tile + bs1 + so[mt]));
+        }
+      }
+    };
+    int ch = wave;
+    if (ch * 32 < npairs) {
+      int bs0, bs1, zo0, zo1;
+      addr(ch, bs0, bs1, zo0, zo1);
+      bf16x8 bz = load_z(zo0, zo1);
+      load_a(bs0, bs1, 0, a0[0], a1[0]);
+      for (bool more = true; more;) {
+        const int nch = ch + 4;
+        more = nch * 32 < npairs;
+        int nb0 = 0, nb1 = 0, nz0 = 0, nz1 = 0;
+        if (more) addr(nch, nb0, nb1, nz0, nz1);
+        bf16x8 bzn = bz;
+#pragma unroll
+        for (int grp = 0; grp < NG; ++grp) {
+          const int cur = grp & 1, nxt = cur ^ 1;
+          if (grp + 1 < NG) load_a(bs0, bs1, grp + 1, a0[nxt], a1[nxt]);
+          else if (more) { bzn = load_z(nz0, nz1); load_a(nb0, nb1, 0, a0[nxt], a1[nxt]); }
+          __builtin_amdgcn_sched_barrier(0);
+          if (grp == 0) accb = cm_mfma(ones, bz, accb);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int mt = 4 * grp + u;
+            if (mt < NMT) acc[mt] = cm_mfma(__builtin_shufflevector(a0[cur][u], a1[cur][u], 0, 1, 2, 3, 4, 5, 6, 7), bz, acc[mt]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        bz = bzn; bs0 = nb0; bs1 = nb1; ch = nch;
+      }
+    }
+  }
+  // four waves' partial sums -> red[0] (fixed order), then dK[kh][kw][ci][co] = D[slot (kh, kw)][ci][2 co] + D[slot (kh, kw + 1)][ci][2 co + 1]
+  __syncthreads();
+  cm_f32x4 *red = reinterpret_cast<cm_f32x4 *>(cm_lds);
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt) red[(wave * (NMT + 1) + mt) * 64 + lane] = acc[mt];
+  red[(wave * (NMT + 1) + NMT) * 64 + lane] = accb;
+  __syncthreads();
+  for (int mt = wave; mt <= NMT; mt += 4) {
+    cm_f32x4 t = red[(0 * (NMT + 1) + mt) * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) t += red[(w * (NMT + 1) + mt) * 64 + lane];
+    red[mt * 64 + lane] = t;                     // wave 0's slot of tile mt: only this wave touches tile mt here
+  }
+  __syncthreads();
+  const float *D = reinterpret_cast<const float *>(cm_lds);   // D[(mt * 64 + g * 16 + n16) * 4 + i]: slot 4 mt + g, channel i, column n16
+  float *dst = part + ((size_t)e * gridDim.x + blockIdx.x) * (25 * CIN * COUT + COUT);
+  for (int i = tid; i < 25 * CIN * COUT + COUT; i += 256) {
+    float v;
+    if (i < 25 * CIN * COUT) {
+      const int co = i % COUT, ci = (i / COUT) % CIN, tap = i / (COUT * CIN);
+      const int kh = tap / 5, kw = tap % 5, s0 = 6 * kh + kw, s1 = s0 + 1;
+      v = D[(((s0 >> 2) * 64 + (s0 & 3) * 16 + 2 * co) * 4) + ci] + D[(((s1 >> 2) * 64 + (s1 & 3) * 16 + 2 * co + 1) * 4) + ci];
+    } else {
+      const int co = i - 25 * CIN * COUT;         // ones row: every row of the bias tile is the column sum; row 0 = lanes g = 0, register 0
+      v = D[((NMT * 64 + 2 * co) * 4)] + D[((NMT * 64 + 2 * co + 1) * 4)];
+    }
+    dst[i] = v;
+  }
+}
+
 // LDS bytes of the three kernels for a geometry (host side)
 static inline size_t cm_lds_fwd(int mode, int H, int W, int pad, int CIN, int COUT) {
   const int pb = mode == CM_IN4 ? 8 : 16;
   return std::max((size_t)((H + 2 * pad) * (W + 2 * pad) + 8) * pb, (size_t)25 * CIN * COUT * 4);
 }
 static inline size_t cm_lds_dx(int Ho, int Wo, int CIN, int COUT) { return std::max((size_t)(Ho + 8) * (Wo + 8) * 32, (size_t)25 * CIN * COUT * 4); }
+static inline size_t cm_lds_dx2x(int Ho, int Wo, int CIN, int COUT) {
+  return std::max((size_t)((Ho + 8) * (Wo + 8) + 8) * 32, (size_t)25 * CIN * COUT * 4);
+}
+static inline size_t cm_lds_dw2x(int H, int W, int pad) {
+  const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4, npairs = Ho * ((Wo + 1) / 2);
+  const size_t tiles = ((size_t)((H + 2 * pad) * (W + 2 * pad) + 8) * 8 + 15) / 16 * 16 + (size_t)((npairs + 31) / 32 * 32) * 32;
+  const size_t red = (size_t)4 * (8 + 1) * 64 * 16;
+  return tiles > red ? tiles : red;
+}
 static inline size_t cm_lds_dw(int mode, int H, int W, int pad) {
   const int pb = mode == CM_IN4 ? 8 : 16, ns = mode == CM_IN4 ? 30 : 50;
   const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4;
