@@ -182,7 +182,8 @@ int32_t mile_set_data(mile_sampler *s, const float *X, const void *y, int64_t N,
 /* Restrict the likelihood to rows [begin, begin + count) of the training set for the following mile_logpost_grad calls
  * (count = 0: all rows again).  Replaces the minibatches of the warm-start stage: loader.iter(split='train', batch_size=...)
  * (src/dataset/tabular.py:170-212) feeding single_step_regr / single_step_class (src/training/trainer.py:706-760).
- * Supported by MILE_GRAD_GENERIC and the MFMA_W64 kernels; the MCLMC path itself is full-batch (n_batches = 1). */
+ * Supported by MILE_GRAD_GENERIC, the MFMA_W64, MFMA_WIDE and LENET kernels (mile_logpost_grad fails with MILE_ERR_STATE on
+ * MFMA_W128_BF16 / GEMM_F32 under a window); the MCLMC path itself is full-batch (n_batches = 1). */
 int32_t mile_set_row_window(mile_sampler *s, int64_t begin, int64_t count);
 
 /* Size the internal workspace (partial-gradient slabs etc.) for ensembles of up to E

@@ -984,7 +984,7 @@ static hipError_t launch_mm3_dw(const MMParams &p, int batch, hipStream_t st) {
 template <int TERMS>
 static int launch_grad_wide(mile_sampler *s, const GradParams &gp, int E, hipStream_t st) {
   const DevSpec &ds = s->ds;
-  const int L = ds.n_layers, d = ds.d, N = s->N, Fp = s->Fp;
+  const int L = ds.n_layers, d = ds.d, N = gp.N, Fp = s->Fp;   // gp.N < s->N under a row window (workspace sized for the whole set)
   auto up8 = [](int v) { return (v + 7) / 8 * 8; };
   int wp[MILE_MAX_LAYERS], fin[MILE_MAX_LAYERS], finp[MILE_MAX_LAYERS];
   size_t per_row = 0, wt_elems = 0, wt_off[MILE_MAX_LAYERS];
@@ -1003,10 +1003,11 @@ static int launch_grad_wide(mile_sampler *s, const GradParams &gp, int E, hipStr
     double gb = 16.0;
     if (const char *ev = getenv("MILE_WIDE_WS_GB")) gb = std::max(0.001, atof(ev));
     const size_t budget = (size_t)(gb * (double)(1ull << 30) / 4.0);
+    const size_t Nall = (size_t)s->N;   // sized for the whole data set, also when the first call comes under a row window
     size_t R = budget / ((size_t)E * per_row);
-    R = std::min<size_t>(std::max<size_t>(R, 128), (size_t)N);
-    if (R < (size_t)N) R = std::max<size_t>(128, R / 128 * 128);
-    if (const char *rv = getenv("MILE_GEMM_ROWS")) R = std::max<size_t>(1, std::min<size_t>((size_t)atoll(rv), (size_t)N));   // test hook
+    R = std::min<size_t>(std::max<size_t>(R, 128), Nall);
+    if (R < Nall) R = std::max<size_t>(128, R / 128 * 128);
+    if (const char *rv = getenv("MILE_GEMM_ROWS")) R = std::max<size_t>(1, std::min<size_t>((size_t)atoll(rv), Nall));   // test hook
     const size_t need = (size_t)E * R * per_row;
     if (need > s->wide_ws_floats) {
       if (s->wide_ws) (void)hipFree(s->wide_ws);
@@ -1103,8 +1104,10 @@ static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t s
   gp.slabs = s->slabs; gp.llpart = s->llpart;
   gp.N = s->N; gp.Npad = s->Npad; gp.Npb = s->Npb; gp.Fp = s->Fp; gp.S = S; gp.R = generic_R(s->ds); gp.dp = (s->ds.d + 3) / 4 * 4;
   if (s->win_count) {   // minibatch: the same kernels on a shifted view of the rows
-    if (kernel != MILE_GRAD_GENERIC && !is_w64(kernel))
-      return fail(MILE_ERR_STATE, "a row window needs the generic or an MFMA_W64 grad kernel");
+    const bool chunked = kernel == MILE_GRAD_MFMA_WIDE_BF16X3 || kernel == MILE_GRAD_MFMA_WIDE_BF16 || kernel == MILE_GRAD_LENET_F32 ||
+                         kernel == MILE_GRAD_LENET_BF16;   // these walk the rows in chunks anyway: a window is a shorter walk
+    if (kernel != MILE_GRAD_GENERIC && !is_w64(kernel) && !chunked)
+      return fail(MILE_ERR_STATE, "a row window needs the generic, an MFMA_W64, an MFMA_WIDE or a LENET grad kernel");
     if (fused_update) return fail(MILE_ERR_STATE, "row windows are for mile_logpost_grad only");
     const int F = s->spec.in_features;
     gp.X = s->X + (size_t)s->win_begin * F;
@@ -1154,7 +1157,7 @@ static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t s
     else if (fq == 2 && !fz.enabled) e = mile_launch_w64_split_fq2(nh, gp, E, st);   // mile_w64_fq2.hip
     HIP_TRY(e);
   } else if (kernel == MILE_GRAD_LENET_F32 || kernel == MILE_GRAD_LENET_BF16) {
-    const int rc = run_lenet(s, theta, E, gp.X, gp.y, s->N, gp.slabs, gp.dp, gp.llpart, nullptr, 0, st, kernel == MILE_GRAD_LENET_BF16);
+    const int rc = run_lenet(s, theta, E, gp.X, gp.y, gp.N, gp.slabs, gp.dp, gp.llpart, nullptr, 0, st, kernel == MILE_GRAD_LENET_BF16);
     if (rc) return rc;
   } else if (kernel == MILE_GRAD_GEMM_F32) {
     const int rc = launch_grad_gemm(s, gp, E, st);

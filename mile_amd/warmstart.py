@@ -5,10 +5,11 @@ log-likelihood: per epoch the training rows are reshuffled and cut into len // b
 batch_size rows (the remainder is dropped, src/dataset/tabular.py:170-212), every member sees the same batch,
 validation after each epoch, per-member early stopping (`earlystop`, trainer.py:920-939).  Here the gradient comes
 from the HIP engine: the epoch's shuffled copy of the training set is handed to it once (`set_data`) and each
-optimizer step evaluates the members on one contiguous row window of it (`mile_set_row_window`, the generic and
-width-64 MFMA kernels) -- the reference's batches, optimizer, validation schedule and early-stopping rule; only the
-permutation differs (torch's generator instead of JAX's key).  Engines whose grad kernel has no row window (wide /
-bf16 / LeNet) fall back to the same number of FULL-batch steps per epoch (round-1 behaviour, documented deviation).
+optimizer step evaluates the members on one contiguous row window of it (`mile_set_row_window`: the generic, width-64
+MFMA, layer-wise wide-net and LeNet kernels) -- the reference's batches, optimizer, validation schedule and
+early-stopping rule; only the permutation differs (torch's generator instead of JAX's key).  The two kernels without a
+row window (the rocBLAS cross-check path and the width-128 bf16 kernel) fall back to the same number of FULL-batch
+steps per epoch (documented deviation).
 """
 from __future__ import annotations
 
@@ -81,7 +82,7 @@ def train_deep_ensemble(eng, prior, theta0: torch.Tensor, n_train: int, valid_x,
     E = theta.shape[0]
     opt = _Optimizer(optimizer, optimizer_parameters or {}, theta)
     minibatch = bool(batch_size) and batch_size < n_train and train_x is not None and train_y is not None and \
-        eng.grad_kernel in ('generic', 'mfma_w64', 'mfma_w64_bf16x3')
+        eng.grad_kernel in ('generic', 'mfma_w64', 'mfma_w64_bf16x3', 'mfma_wide_bf16x3', 'mfma_wide_bf16', 'lenet_f32', 'lenet_bf16')
     if minibatch:
         n_batches = n_train // batch_size                                    # drop last, tabular.py:190-191
         gen = torch.Generator().manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)

@@ -193,11 +193,18 @@ def test_train_cli_lenet_yaml(tmp_path):
     cfg['data']['path'] = '300x3x16x16'
     cfg['training']['sampler'].update(warmup_steps=200, n_samples=20, n_chains=3, desired_energy_var_start=5e-4,
                                       desired_energy_var_end=1e-4)
+    # warm-start training on minibatches of 32 images (row windows of the bf16 kernel, trainer.py:330-538)
+    cfg['training']['warmstart'] = {'include': True, 'optimizer_config': {'name': 'adamw', 'parameters': {'learning_rate': 0.003}},
+                                    'max_epochs': 3, 'batch_size': 32, 'patience': 2}
     (tmp_path / 'cfg.yaml').write_text(yaml.safe_dump(cfg))
     r = subprocess.run([sys.executable, str(root / 'train.py'), '-c', str(tmp_path / 'cfg.yaml'), '-d', '1'],
                        capture_output=True, text=True, cwd=root, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     exp = tmp_path / 'lenet_small'
+    log = (exp / 'training.log').read_text()
+    assert 'Warmstart Training completed' in log
+    w = np.load(exp / 'warmstart' / 'params_1.npz')
+    assert np.abs(w['core.conv1.bias']).max() > 0 and all(np.isfinite(w[k]).all() for k in w.files)    # trained from zero biases
     assert sorted(p.name for p in (exp / 'samples').iterdir() if p.is_dir()) == ['0', '1', '2']
     z = np.load(exp / 'samples' / '2' / 'sample_10.npz')
     assert z.files == ['core.conv1.bias', 'core.conv1.kernel', 'core.conv2.bias', 'core.conv2.kernel', 'core.fc1.bias',

@@ -329,3 +329,40 @@ def test_row_window_is_the_minibatch_gradient(oracle, kernel):
     assert torch.equal(lp, full[0]) and torch.equal(g, full[1])
     with pytest.raises(Exception, match='window'):
         eng.set_row_window(N - 3, 7)
+
+
+def test_row_window_on_the_chunked_kernels(oracle):
+    """The layer-wise wide-net kernels and the LeNet kernels walk the rows in chunks anyway: a window is a shorter walk (first
+    call under a window, then the full set again); the width-128 bf16 kernel refuses a window."""
+    ospec = oracle.ModelSpec(7, (96, 96, 3), task='classification')
+    N, E = 203, 3
+    prob = oracle.synthetic_problem(ospec, N, E, seed=18)
+    th = torch.from_numpy(prob['theta0'])
+    eng = _engine(oracle, ospec, prob, 'mfma_wide_bf16x3')
+    for begin, count in ((40, 32), (0, 0), (N - 9, 9)):
+        eng.set_row_window(begin, count)
+        sl = slice(begin, begin + count) if count else slice(None)
+        lp, g = eng.logpost_grad(th)
+        lp_ref, g_ref = oracle.logpost_and_grad(ospec, prob['theta0'].astype(np.float64), prob['X'][sl], prob['y'][sl])
+        assert _relerr(lp.cpu().numpy(), lp_ref) < 2e-5 and _relerr(g.cpu().numpy(), g_ref) < 2e-5, (begin, count)
+    from oracle import lenet_oracle as LN
+    from mile_amd import LeNetSpec
+    from mile_amd.engine import Engine
+    lspec = LN.LeNetSpec(3, 16, 16, 4)
+    lprob = LN.synthetic_problem(lspec, 41, 2, seed=19)
+    lth = torch.from_numpy(lprob['theta0'])
+    for kernel, tol in (('lenet_f32', 5e-5), ('lenet_bf16', 3e-3)):
+        le = Engine(LeNetSpec(3, 16, 16, 4), torch.from_numpy(lprob['X']), torch.from_numpy(lprob['y']), device='cuda:0', grad_kernel=kernel)
+        f = LN.logpost_and_grad if kernel == 'lenet_f32' else LN.logpost_and_grad_bf16
+        for begin, count in ((10, 16), (0, 0)):
+            le.set_row_window(begin, count)
+            sl = slice(begin, begin + count) if count else slice(None)
+            lp, g = le.logpost_grad(lth)
+            lp_ref, g_ref = f(lspec, lprob['theta0'].astype(np.float64), lprob['X'][sl], lprob['y'][sl])
+            assert _relerr(lp.cpu().numpy(), lp_ref) < 1e-4 and _relerr(g.cpu().numpy(), g_ref) < tol, (kernel, begin, count)
+    bspec = oracle.ModelSpec(9, (128, 128, 2))
+    bprob = oracle.synthetic_problem(bspec, 128, 2, seed=20)
+    be = _engine(oracle, bspec, bprob, 'mfma_w128_bf16')
+    be.set_row_window(0, 64)
+    with pytest.raises(Exception, match='window'):
+        be.logpost_grad(torch.from_numpy(bprob['theta0']))
