@@ -98,6 +98,78 @@ __device__ __forceinline__ float dz_from_pool(const float *dp_img, const float *
   return g * act_bwd(activation, a_img[(y * Wo + x) * C + c]);
 }
 
+// ---- staging helpers of the direct kernels ---------------------------------------------------------------------------
+// U elements / pixels per thread and pass with ALL their global loads issued before the first LDS store: as plain loops
+// (load, store, next) every iteration waited out its own loads' latency -- a dozen serial HBM round trips per image, which
+// was most of these kernels' time (found on the MFMA forms, mile_lenet_mfma.h; round 2).
+typedef float cv_f32x2 __attribute__((ext_vector_type(2)));
+typedef float cv_f32x4 __attribute__((ext_vector_type(4)));
+
+// zero-padded input tile [CIN][Hp][Wp] of one image
+__device__ __forceinline__ void conv_stage_input(float *tile, const float *src, long long sH, long long sW, long long sC, int CIN, int H, int W,
+                                                 int pad, int Hp, int Wp, int tid, int nt) {
+  constexpr int U = 4;
+  const int n = CIN * Hp * Wp;
+  for (int i0 = tid; i0 < n; i0 += nt * U) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + nt * u;
+      const int xx = i % Wp, yy = (i / Wp) % Hp, ci = i / (Wp * Hp);
+      const int h = yy - pad, w = xx - pad;
+      v[u] = (i < n && h >= 0 && h < H && w >= 0 && w < W) ? src[h * sH + w * sW + ci * sC] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (i0 + nt * u < n) tile[i0 + nt * u] = v[u];
+  }
+}
+
+// dZ tile(s): dst[(img * Ht + y + halo) * Wt + x + halo][COUT] for ni images, Ht = Ho + 2 halo, Wt = Wo + 2 halo, zero halo;
+// dz = unpool(dp) * act'(a) as dz_from_pool.  One pixel per thread and pass, its channels as 8- / 16-byte loads (the a / dp
+// arrays are 16-byte aligned and COUT is even).
+template <int COUT>
+__device__ __forceinline__ void conv_stage_dz(float *dst, const float *dp0, const float *a0, int ni, int Ho, int Wo, int halo, int activation,
+                                              int tid, int nt) {
+  static_assert(COUT % 2 == 0, "channel pairs");
+  constexpr int U = COUT > 8 ? 2 : 4, VW = COUT % 4 == 0 ? 4 : 2;
+  const int Wt = Wo + 2 * halo, Ht = Ho + 2 * halo, Hq = Ho / 2, Wq = Wo / 2, per = Ht * Wt, n = ni * per;
+  for (int i0 = tid; i0 < n; i0 += nt * U) {
+    float av[U][COUT], gv[U][COUT];
+    bool in[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + nt * u;
+      const int im = i / per, r = i - im * per, yy = r / Wt, xx = r - yy * Wt, y = yy - halo, x = xx - halo;
+      in[u] = i < n && y >= 0 && y < Ho && x >= 0 && x < Wo;
+      const bool pin = in[u] && y < 2 * Hq && x < 2 * Wq;
+      const float *ap = a0 + ((size_t)(in[u] ? im : 0) * Ho * Wo + (in[u] ? y * Wo + x : 0)) * COUT;
+      const float *gp = dp0 + ((size_t)(pin ? im : 0) * Hq * Wq + (pin ? (y >> 1) * Wq + (x >> 1) : 0)) * COUT;
+#pragma unroll
+      for (int c = 0; c < COUT; c += VW) {
+        if constexpr (VW == 4) {
+          const cv_f32x4 ta = *(const cv_f32x4 *)(ap + c);
+          const cv_f32x4 tg = pin ? *(const cv_f32x4 *)(gp + c) : cv_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { av[u][c + k] = ta[k]; gv[u][c + k] = tg[k]; }
+        } else {
+          const cv_f32x2 ta = *(const cv_f32x2 *)(ap + c);
+          const cv_f32x2 tg = pin ? *(const cv_f32x2 *)(gp + c) : cv_f32x2{0.0f, 0.0f};
+          av[u][c] = ta[0]; av[u][c + 1] = ta[1]; gv[u][c] = tg[0]; gv[u][c + 1] = tg[1];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + nt * u;
+      if (i >= n) continue;
+      float *o = dst + (size_t)i * COUT;
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) o[c] = in[u] ? 0.25f * gv[u][c] * act_bwd(activation, av[u][c]) : 0.0f;
+    }
+  }
+}
+
 // Compile-time geometries of the two common inputs (GEO = 0: everything at run time).  With the extents known the
 // tap offsets inside a tile become immediates of the LDS instructions instead of per-tap VALU address arithmetic
 // (the counters showed 4-6x more VALU instructions than FMAs in the run-time form).
@@ -135,12 +207,7 @@ __global__ __launch_bounds__(256) void k_conv5_fwd(const float *in, long long sE
   const int b0 = blockIdx.x * ipw, b1 = min(R, b0 + ipw);
   for (int b = b0; b < b1; ++b) {
     __syncthreads();
-    const float *src = in + (size_t)e * sE + (size_t)b * sB;
-    for (int i = tid; i < CIN * Hp * Wp; i += 256) {
-      const int xx = i % Wp, yy = (i / Wp) % Hp, ci = i / (Wp * Hp);
-      const int h = yy - pad, w = xx - pad;
-      tile[i] = (h >= 0 && h < H && w >= 0 && w < W) ? src[h * sH + w * sW + ci * sC] : 0.0f;
-    }
+    conv_stage_input(tile, in + (size_t)e * sE + (size_t)b * sB, sH, sW, sC, CIN, H, W, pad, Hp, Wp, tid, 256);
     __syncthreads();
     float *dst = out + ((size_t)e * R + b) * Ho * Wo * COUT;
     for (int p = tid; p < Ho * Wo; p += 256) {
@@ -184,13 +251,9 @@ __global__ __launch_bounds__(256) void k_conv5_dx(const float *dp, const float *
   for (int bb = b0; bb < b1; bb += NI) {
     const int ni = min(NI, b1 - bb);
     __syncthreads();
-    for (int i = tid; i < ni * Ht * Wt * COUT; i += 256) {
-      const int c = i % COUT, xx = (i / COUT) % Wt, yy = (i / (COUT * Wt)) % Ht, im = i / (COUT * Wt * Ht);
-      const int y = yy - 4, x = xx - 4;
-      const size_t img = (size_t)e * R + bb + im;
-      tile[i] = (y >= 0 && y < Ho && x >= 0 && x < Wo)
-                    ? dz_from_pool(dp + img * (Ho / 2) * (Wo / 2) * COUT, a + img * Ho * Wo * COUT, y, x, c, Ho, Wo, COUT, activation)
-                    : 0.0f;
+    {
+      const size_t img0 = (size_t)e * R + bb;
+      conv_stage_dz<COUT>(tile, dp + img0 * (Ho / 2) * (Wo / 2) * COUT, a + img0 * Ho * Wo * COUT, ni, Ho, Wo, 4, activation, tid, 256);
     }
     __syncthreads();
     const int total = ni * npix;
@@ -266,18 +329,9 @@ __global__ __launch_bounds__(256) void k_conv5_dw(const float *in, long long sE,
   const int b0 = blockIdx.x * ipw, b1 = min(R, b0 + ipw);
   for (int b = b0; b < b1; ++b) {
     __syncthreads();
-    const float *src = in + (size_t)e * sE + (size_t)b * sB;
-    for (int i = tid; i < CIN * Hp * Wp; i += nt) {
-      const int xx = i % Wp, yy = (i / Wp) % Hp, c2 = i / (Wp * Hp);
-      const int h = yy - pad, w = xx - pad;
-      tile[i] = (h >= 0 && h < H && w >= 0 && w < W) ? src[h * sH + w * sW + c2 * sC] : 0.0f;
-    }
+    conv_stage_input(tile, in + (size_t)e * sE + (size_t)b * sB, sH, sW, sC, CIN, H, W, pad, Hp, Wp, tid, nt);
     const size_t img = (size_t)e * R + b;
-    const float *dp_img = dp + img * (Ho / 2) * (Wo / 2) * COUT, *a_img = a + img * Ho * Wo * COUT;
-    for (int i = tid; i < Ho * Wo * COUT; i += nt) {
-      const int c = i % COUT, px = i / COUT;
-      zt[i] = dz_from_pool(dp_img, a_img, px / Wo, px % Wo, c, Ho, Wo, COUT, activation);
-    }
+    conv_stage_dz<COUT>(zt, dp + img * (Ho / 2) * (Wo / 2) * COUT, a + img * Ho * Wo * COUT, 1, Ho, Wo, 0, activation, tid, nt);
     __syncthreads();
     if (active)
       for (int p = g; p < Ho * Wo; p += G) {
