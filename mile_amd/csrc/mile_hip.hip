@@ -622,6 +622,13 @@ __global__ void k_fill(float *p, float v, int n) {
 // LeNet: forward (+ backward when slab != nullptr) over image chunks; batch = particles (or samples).
 // out_ll != nullptr: evaluation, per-row log-likelihoods out_ll[(s0 + e) * N + r]; otherwise the gradient goes
 // to slab[e * dp + offset] and the log-likelihood sums to llacc[e].
+// Dense half of LeNet on the hand-written MFMA GEMMs (k_mm3 with fp32-faithful three-term products; defined below the k_mm3
+// launchers): LENET_BF16 uses no library kernel.  lenet_dense_prep once per gradient, lenet_dense_chunk per image chunk.
+struct LeNetDenseBufs { const float *p2; float *f1, *f2, *out, *df2, *df1, *dp2; };
+static int lenet_dense_prep(mile_sampler *s, const float *theta, int E, hipStream_t st);
+static int lenet_dense_chunk(mile_sampler *s, const float *theta, int E, int Rc, int r0, int chunk, const LeNetDenseBufs &b, const void *y,
+                             float *slab, long long dp, float *llacc, float *out_ll, long long Ntot, long long s0, hipStream_t st);
+
 static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X, const void *y, int N, float *slab, long long dp,
                      float *llacc, float *out_ll, long long s0, hipStream_t st, bool mfma = false) {
   if (!rocblas_load()) return fail(MILE_ERR_HIP, "librocblas.so could not be loaded");
@@ -634,7 +641,7 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
   const size_t n_a1 = 6 * HW, n_p1 = 6 * P1, n_col2 = 150 * HW2, n_a2 = 16 * HW2, n_p2 = g.flat;
   // direct convolution kernels (LDS tiles per image) unless the image is too large for them or the im2col + SGEMM
   // form is asked for (MILE_LENET_GEMM=1: kept as the second implementation / fallback)
-  const int ipw = getenv("MILE_LENET_IPW") ? std::max(1, atoi(getenv("MILE_LENET_IPW"))) : 8;   // images per workgroup (dev knob)
+  const int ipw = getenv("MILE_LENET_IPW") ? std::max(1, atoi(getenv("MILE_LENET_IPW"))) : (mfma ? 16 : 8);   // images per workgroup (measured: 53.0 / 54.7 ms at 16 / 8 on the MFMA forms)
   const size_t lds_f1 = (size_t)(25 * g.C * 8 + 8 + g.C * (g.H + 4) * (g.W + 4)) * 4;
   const int KT1 = 25 * g.C;
   // k_conv5_dw: pixel groups are reduced 3 at a time through LDS (buffer aliases the tiles)
@@ -653,8 +660,10 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
   const size_t ldm_x2p = cm_lds_dx2x(g.h2, g.w2, 6, 16), ldm_w1p = cm_lds_dw2x(g.H, g.W, 2);
   if (mfma && (!direct || g.C > 4 || std::max({ldm_f1, ldm_f2, ldm_x2, ldm_w1, ldm_w2, ldm_x2p, ldm_w1p}) > 150 * 1024))
     return fail(MILE_ERR_INVALID, "LENET_BF16 needs <= 4 image channels and an image that fits the LDS tiles");
-  size_t per = n_a1 + n_p1 + (direct ? 0 : n_col2) + n_a2 + n_p2 + 120 + 84 + g.K;
-  if (grad) per += 84 + 120 + n_p2 + n_p1 + (direct ? 0 : n_a2 + n_a1);
+  // Dense activations: exact widths on the rocBLAS path; k_mm3 wants rows of 8 k floats (zero padding columns)
+  const size_t w_f2 = mfma ? 88 : 84, w_out = mfma ? (size_t)(g.K + 7) / 8 * 8 : (size_t)g.K;
+  size_t per = n_a1 + n_p1 + (direct ? 0 : n_col2) + n_a2 + n_p2 + 120 + w_f2 + w_out;
+  if (grad) per += w_f2 + 120 + n_p2 + n_p1 + (direct ? 0 : n_a2 + n_a1);
   const size_t shared = direct ? 0 : 25 * (size_t)g.C * HW;
   size_t R = ((size_t)1 << 30) / ((size_t)E * per + shared);
   R = std::max<size_t>(1, std::min<size_t>(R, (size_t)N));
@@ -682,9 +691,9 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
   float *q = s->gemm_ws;
   auto take = [&](size_t n) { float *r = q; q += (n + 3) / 4 * 4; return r; };   // every array 16-byte aligned (vector loads in the conv kernels)
   float *col1 = take(R * shared), *a1 = take(ER * n_a1), *p1 = take(ER * n_p1), *col2 = take(direct ? 0 : ER * n_col2), *a2 = take(ER * n_a2);
-  float *p2 = take(ER * n_p2), *f1 = take(ER * 120), *f2 = take(ER * 84), *out = take(ER * g.K);
+  float *p2 = take(ER * n_p2), *f1 = take(ER * 120), *f2 = take(ER * w_f2), *out = take(ER * w_out);
   float *df2 = nullptr, *df1 = nullptr, *dp2 = nullptr, *dz2 = nullptr, *dp1 = nullptr, *dz1 = nullptr;
-  if (grad) { df2 = take(ER * 84); df1 = take(ER * 120); dp2 = take(ER * n_p2); dz2 = take(direct ? 0 : ER * n_a2); dp1 = take(ER * n_p1); dz1 = take(direct ? 0 : ER * n_a1); }
+  if (grad) { df2 = take(ER * w_f2); df1 = take(ER * 120); dp2 = take(ER * n_p2); dz2 = take(direct ? 0 : ER * n_a2); dp1 = take(ER * n_p1); dz1 = take(direct ? 0 : ER * n_a1); }
   float *part1 = take(n_part1), *part2 = take(n_part2);
   if (direct) {
     static bool attr_done = false;
@@ -716,6 +725,12 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
   auto bias_act = [&](float *z, int b_off, int W, long long rows, int apply) {
     k_gemm_bias_act<<<dim3(blocks(rows * W), E), 256, 0, st>>>(z, theta, b_off, d, W, rows * W, act, apply);
   };
+  if (mfma) {   // padding columns of the Dense activations are read as operands: zero them (never written afterwards)
+    HIP_TRY(hipMemsetAsync(f1, 0, (ER * 120 + 4 + ER * w_f2 + 4 + ER * w_out) * 4, st));
+    if (grad) HIP_TRY(hipMemsetAsync(df2, 0, (ER * w_f2 + 4 + ER * 120) * 4, st));
+    const int rc = lenet_dense_prep(s, theta, E, st);
+    if (rc) return rc;
+  }
   for (int r0 = 0, chunk = 0; r0 < N; r0 += (int)R, ++chunk) {
     const long long Rc = std::min<long long>((long long)R, N - r0), B = (long long)E * Rc;
     const long long M1 = Rc * (long long)HW, M2 = Rc * (long long)HW2;
@@ -744,17 +759,24 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
       bias_act(a2, g.b_c2, 16, M2, 1);
     }
     if (!mfma) k_avgpool2<<<blocks(B * (long long)n_p2), 256, 0, st>>>(a2, p2, B, g.h2, g.w2, 16);
-    if (fwd(g.k_f1, g.flat, 120, p2, Rc * g.flat, Rc, f1)) return fail(MILE_ERR_HIP, "rocblas sgemm (fc1) failed");
-    bias_act(f1, g.b_f1, 120, Rc, 1);
-    if (fwd(g.k_f2, 120, 84, f1, Rc * 120, Rc, f2)) return fail(MILE_ERR_HIP, "rocblas sgemm (fc2) failed");
-    bias_act(f2, g.b_f2, 84, Rc, 1);
-    if (fwd(g.k_f3, 84, g.K, f2, Rc * 84, Rc, out)) return fail(MILE_ERR_HIP, "rocblas sgemm (fc3) failed");
-    bias_act(out, g.b_f3, g.K, Rc, 0);
-    if (!grad) {
-      k_gemm_rowll<<<dim3((unsigned)((Rc + 255) / 256), E), 256, 0, st>>>(out, y, r0, (int)Rc, g.K, task, out_ll, N, s0);
-      continue;
+    if (mfma) {   // Dense layers, head and their backward pass on k_mm3; leaves dp2 for the convolution backward pass below
+      const LeNetDenseBufs db{p2, f1, f2, out, df2, df1, dp2};
+      const int rc = lenet_dense_chunk(s, theta, E, (int)Rc, r0, chunk, db, y, slab, dp, llacc, out_ll, N, s0, st);
+      if (rc) return rc;
+      if (!grad) continue;
+    } else {
+      if (fwd(g.k_f1, g.flat, 120, p2, Rc * g.flat, Rc, f1)) return fail(MILE_ERR_HIP, "rocblas sgemm (fc1) failed");
+      bias_act(f1, g.b_f1, 120, Rc, 1);
+      if (fwd(g.k_f2, 120, 84, f1, Rc * 120, Rc, f2)) return fail(MILE_ERR_HIP, "rocblas sgemm (fc2) failed");
+      bias_act(f2, g.b_f2, 84, Rc, 1);
+      if (fwd(g.k_f3, 84, g.K, f2, Rc * 84, Rc, out)) return fail(MILE_ERR_HIP, "rocblas sgemm (fc3) failed");
+      bias_act(out, g.b_f3, g.K, Rc, 0);
+      if (!grad) {
+        k_gemm_rowll<<<dim3((unsigned)((Rc + 255) / 256), E), 256, 0, st>>>(out, y, r0, (int)Rc, g.K, task, out_ll, N, s0);
+        continue;
+      }
+      k_gemm_head<<<E, 256, 0, st>>>(out, y, r0, (int)Rc, g.K, task, llacc, chunk == 0);
     }
-    k_gemm_head<<<E, 256, 0, st>>>(out, y, r0, (int)Rc, g.K, task, llacc, chunk == 0);
     // ---- backward
     const float *beta = chunk == 0 ? &zero : &one;
     // dW[fin x fout] (+)= in^T dz into the slab; bias gradient = dz^T 1
@@ -773,14 +795,16 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
     auto act_grad = [&](float *dh, const float *h, long long n) {
       k_gemm_act_grad<<<dim3(blocks(n), E), 256, 0, st>>>(dh, h, n, act);
     };
-    if (dW(g.k_f3, g.b_f3, 84, g.K, f2, Rc * 84, out, Rc)) return fail(MILE_ERR_HIP, "rocblas sgemm (d fc3) failed");
-    if (dX(g.k_f3, 84, g.K, out, Rc, df2)) return fail(MILE_ERR_HIP, "rocblas sgemm (d fc3 in) failed");
-    act_grad(df2, f2, Rc * 84);
-    if (dW(g.k_f2, g.b_f2, 120, 84, f1, Rc * 120, df2, Rc)) return fail(MILE_ERR_HIP, "rocblas sgemm (d fc2) failed");
-    if (dX(g.k_f2, 120, 84, df2, Rc, df1)) return fail(MILE_ERR_HIP, "rocblas sgemm (d fc2 in) failed");
-    act_grad(df1, f1, Rc * 120);
-    if (dW(g.k_f1, g.b_f1, g.flat, 120, p2, Rc * g.flat, df1, Rc)) return fail(MILE_ERR_HIP, "rocblas sgemm (d fc1) failed");
-    if (dX(g.k_f1, g.flat, 120, df1, Rc, dp2)) return fail(MILE_ERR_HIP, "rocblas sgemm (d fc1 in) failed");
+    if (!mfma) {
+      if (dW(g.k_f3, g.b_f3, 84, g.K, f2, Rc * 84, out, Rc)) return fail(MILE_ERR_HIP, "rocblas sgemm (d fc3) failed");
+      if (dX(g.k_f3, 84, g.K, out, Rc, df2)) return fail(MILE_ERR_HIP, "rocblas sgemm (d fc3 in) failed");
+      act_grad(df2, f2, Rc * 84);
+      if (dW(g.k_f2, g.b_f2, 120, 84, f1, Rc * 120, df2, Rc)) return fail(MILE_ERR_HIP, "rocblas sgemm (d fc2) failed");
+      if (dX(g.k_f2, 120, 84, df2, Rc, df1)) return fail(MILE_ERR_HIP, "rocblas sgemm (d fc2 in) failed");
+      act_grad(df1, f1, Rc * 120);
+      if (dW(g.k_f1, g.b_f1, g.flat, 120, p2, Rc * g.flat, df1, Rc)) return fail(MILE_ERR_HIP, "rocblas sgemm (d fc1) failed");
+      if (dX(g.k_f1, g.flat, 120, df1, Rc, dp2)) return fail(MILE_ERR_HIP, "rocblas sgemm (d fc1 in) failed");
+    }
     if (!direct) k_unpool_actgrad<<<blocks(B * (long long)n_a2), 256, 0, st>>>(dp2, a2, dz2, B, g.h2, g.w2, 16, act);
     if (direct) {   // dZ = unpool(dP) * act'(A) is formed inside the kernels' tile loads: no dz2 / dz1 arrays
       const int acc = chunk != 0;
@@ -979,6 +1003,91 @@ template <int TERMS>
 static hipError_t launch_mm3_dw(const MMParams &p, int batch, hipStream_t st) {
   return p.accumulate ? launch_mm3_k<MM_A_KM, MM_B_F32_KN, MM_EPI_STORE, TERMS, -1, true, true>(p, batch, st)
                       : launch_mm3_k<MM_A_KM, MM_B_F32_KN, MM_EPI_STORE, TERMS, -1, false, true>(p, batch, st);
+}
+
+// ---- Dense half of LeNet (flat -> 120 -> 84 -> K) on k_mm3, TERMS = 3: the weights as zero-padded bf16 term planes in
+// s->wide_wt [E][layer][term][in][outp], activations [E][Rc][ld] with ld = 120 / 88 / up8(K)
+static void lenet_dense_dims(const LeNetGeom &g, int (&fin)[3], int (&fout)[3], int (&ld)[3], int (&woff)[3], int (&boff)[3], size_t (&pl)[3],
+                             size_t &elems) {
+  fin[0] = g.flat; fin[1] = 120; fin[2] = 84;
+  fout[0] = 120; fout[1] = 84; fout[2] = g.K;
+  woff[0] = g.k_f1; woff[1] = g.k_f2; woff[2] = g.k_f3;
+  boff[0] = g.b_f1; boff[1] = g.b_f2; boff[2] = g.b_f3;
+  elems = 0;
+  for (int l = 0; l < 3; ++l) { ld[l] = (fout[l] + 7) / 8 * 8; pl[l] = elems; elems += (size_t)3 * fin[l] * ld[l]; }
+}
+static int lenet_dense_prep(mile_sampler *s, const float *theta, int E, hipStream_t st) {
+  int fin[3], fout[3], ld[3], woff[3], boff[3]; size_t pl[3], elems;
+  lenet_dense_dims(s->lg, fin, fout, ld, woff, boff, pl, elems);
+  const size_t bytes = (size_t)E * elems * 2;
+  if (bytes > s->wide_wt_bytes) {
+    if (s->wide_wt) (void)hipFree(s->wide_wt);
+    s->wide_wt = nullptr; s->wide_wt_bytes = 0;
+    HIP_TRY(hipMalloc(&s->wide_wt, bytes));
+    s->wide_wt_bytes = bytes;
+  }
+  for (int l = 0; l < 3; ++l) {
+    const long long plane = (long long)fin[l] * ld[l];
+    k_wide_prep_weights<3><<<dim3((unsigned)std::min<long long>((plane + 255) / 256, 1024), E), 256, 0, st>>>(
+        theta, s->lg.d, woff[l], fin[l], fout[l], ld[l], (bf16 *)s->wide_wt + pl[l], (long long)elems);
+  }
+  HIP_TRY(hipGetLastError());
+  return MILE_OK;
+}
+static int lenet_dense_chunk(mile_sampler *s, const float *theta, int E, int Rc, int r0, int chunk, const LeNetDenseBufs &b, const void *y,
+                             float *slab, long long dp, float *llacc, float *out_ll, long long Ntot, long long s0, hipStream_t st) {
+  const LeNetGeom &g = s->lg;
+  int fin[3], fout[3], ld[3], woff[3], boff[3]; size_t pl[3], elems;
+  lenet_dense_dims(g, fin, fout, ld, woff, boff, pl, elems);
+  const bf16 *Wt = (const bf16 *)s->wide_wt;
+  const int act = s->ds.activation, task = s->ds.task, d = g.d;
+  const float *in[3] = {b.p2, b.f1, b.f2};
+  const int ldin[3] = {g.flat, ld[0], ld[1]};
+  float *H[3] = {b.f1, b.f2, b.out};
+  for (int l = 0; l < 3; ++l) {   // forward: H_l = act(in W_l + b_l), no activation on the head
+    MMParams p{};
+    p.A = in[l]; p.sA = (long long)Rc * ldin[l]; p.lda = ldin[l]; p.K = fin[l];
+    p.B = Wt + pl[l]; p.sB = (long long)elems; p.ldb = ld[l]; p.tB = (long long)fin[l] * ld[l];
+    p.C = H[l]; p.sC = (long long)Rc * ld[l]; p.ldc = ld[l];
+    p.M = Rc; p.N = fout[l];
+    p.bias = theta + boff[l]; p.sBias = d;
+    p.act = act; p.apply_act = l < 2;
+    HIP_TRY(launch_mm3_fwd<3>(p, E, st));
+  }
+  if (!slab) {   // evaluation: per-row log-likelihood
+    k_wide_rowll<<<dim3((unsigned)((Rc + 255) / 256), E), 256, 0, st>>>(b.out, (long long)Rc * ld[2], ld[2], y, r0, Rc, g.K, task, out_ll, Ntot, s0);
+    HIP_TRY(hipGetLastError());
+    return MILE_OK;
+  }
+  k_wide_head<<<E, 256, 0, st>>>(b.out, (long long)Rc * ld[2], ld[2], y, r0, Rc, g.K, task, llacc, chunk == 0);
+  float *dz[3] = {b.df1, b.df2, b.out};      // dZ of layer l (the head's d(out) is in place)
+  for (int l = 2; l >= 0; --l) {
+    {  // dW_l (+)= in^T dZ_l into the slab, bias gradient from the same B tiles
+      MMParams p{};
+      p.A = in[l]; p.sA = (long long)Rc * ldin[l]; p.lda = ldin[l];
+      p.B = dz[l]; p.sB = (long long)Rc * ld[l]; p.ldb = ld[l];
+      p.C = slab + woff[l]; p.sC = dp; p.ldc = fout[l];
+      p.M = fin[l]; p.N = fout[l]; p.K = Rc;
+      p.accumulate = chunk != 0;
+      p.colsum = slab + boff[l]; p.sColsum = dp;
+      HIP_TRY(launch_mm3_dw<3>(p, E, st));
+    }
+    MMParams p{};   // d(in) = dZ_l W_l^T, times act'(in) for the Dense inputs; the pooled conv output takes it as is
+    p.A = dz[l]; p.sA = (long long)Rc * ld[l]; p.lda = ld[l]; p.K = fout[l];
+    p.B = Wt + pl[l]; p.sB = (long long)elems; p.ldb = ld[l]; p.tB = (long long)fin[l] * ld[l];
+    p.M = Rc; p.N = fin[l];
+    if (l > 0) {
+      p.C = dz[l - 1]; p.sC = (long long)Rc * ldin[l]; p.ldc = ldin[l];
+      p.Hprev = in[l]; p.sH = (long long)Rc * ldin[l]; p.ldh = ldin[l];
+      p.act = act;
+      HIP_TRY(launch_mm3_dh<3>(p, E, st));
+    } else {
+      p.C = b.dp2; p.sC = (long long)Rc * g.flat; p.ldc = g.flat;
+      HIP_TRY((launch_mm3_k<MM_A_MK, MM_B_T3_NK, MM_EPI_STORE, 3, -1, false, false>(p, E, st)));
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return MILE_OK;
 }
 
 template <int TERMS>
@@ -1427,7 +1536,7 @@ int32_t mile_grad_launch_info(const mile_sampler *s, int32_t E, int32_t *grid_x,
     lds = nh == 2 ? (fq == 1 ? w64_lds_bytes<2, 1, true>() : w64_lds_bytes<2, 2, true>())
                   : (fq == 1 ? w64_lds_bytes<3, 1, true>() : w64_lds_bytes<3, 2, true>());
   } else if (kernel == MILE_GRAD_LENET_BF16) {
-    nm = "k_conv5m_fwd/dx/dw (implicit-GEMM bf16 MFMA) + rocblas_sgemm_strided_batched (Dense)";
+    nm = "k_conv5m_fwd/dx/dw (implicit-GEMM bf16 MFMA) + k_mm3 (Dense, fp32-faithful three-term products)";
     lds = (int)cm_lds_dw(CM_IN8, s->lg.hp1, s->lg.wp1, 0);
   } else if (kernel == MILE_GRAD_LENET_F32) {
     nm = "rocblas_sgemm_strided_batched+k_im2col5/k_col2im5/k_avgpool2";
