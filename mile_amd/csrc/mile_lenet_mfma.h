@@ -38,6 +38,50 @@ __device__ __forceinline__ uint32_t cm_pack2(float lo, float hi) {   // two floa
   return __builtin_bit_cast(uint32_t, v);
 }
 
+// ReLU activations kept for the backward pass only as "was it positive": two bytes per element, any non-zero value stays non-zero
+// (truncated bf16 with a sticky low bit).  Halves the largest arrays the convolution half moves through HBM.
+__device__ __forceinline__ uint32_t cm_sign_pack2(float lo, float hi) {
+  const uint32_t a = __float_as_uint(lo), b = __float_as_uint(hi);
+  return ((a >> 16) | ((a & 0xffffu) ? 1u : 0u)) | (((b >> 16) | ((b & 0xffffu) ? 1u : 0u)) << 16);
+}
+// COUT-vector loads of one pixel's activations: fp32 (8- / 16-byte loads) or the two-byte form above
+template <int COUT, bool A16>
+__device__ __forceinline__ void cm_load_act(const void *a_img, size_t pixel, float (&av)[COUT]) {
+  if constexpr (A16) {
+    const uint32_t *ap = reinterpret_cast<const uint32_t *>(a_img) + pixel * (COUT / 2);
+    if constexpr (COUT % 8 == 0) {
+#pragma unroll
+      for (int c = 0; c < COUT; c += 8) {
+        const cm_u32x4 t = *reinterpret_cast<const cm_u32x4 *>(ap + c / 2);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { av[c + 2 * k] = __uint_as_float(t[k] << 16); av[c + 2 * k + 1] = __uint_as_float(t[k] & 0xffff0000u); }
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < COUT; c += 2) {
+        const uint32_t t = ap[c / 2];
+        av[c] = __uint_as_float(t << 16); av[c + 1] = __uint_as_float(t & 0xffff0000u);
+      }
+    }
+  } else {
+    const float *ap = reinterpret_cast<const float *>(a_img) + pixel * COUT;
+    if constexpr (COUT % 4 == 0) {
+#pragma unroll
+      for (int c = 0; c < COUT; c += 4) {
+        const cm_f32x4 t = *reinterpret_cast<const cm_f32x4 *>(ap + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) av[c + k] = t[k];
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < COUT; c += 2) {
+        const cm_f32x2 t = *reinterpret_cast<const cm_f32x2 *>(ap + c);
+        av[c] = t[0]; av[c + 1] = t[1];
+      }
+    }
+  }
+}
+
 // p / w for 0 <= p < 2^20 with inv = 1.0f / w (exact: the quotient's distance from an integer is >= 1 / (2 w) >> the float error)
 __device__ __forceinline__ int cm_div(int p, float inv) { return (int)(((float)p + 0.5f) * inv); }
 
@@ -235,7 +279,7 @@ __device__ __forceinline__ void cm_image_f(const char *tile, int ntiles, int wav
 template <int MODE, int COUT>
 __global__ __launch_bounds__(256) void k_conv5m_fwd(const float *in, long long sE, long long sB, long long sH, long long sW, long long sC,
                                                     int CIN, int H, int W, int pad, const float *theta, int k_off, int b_off, int d, float *out,
-                                                    float *pool, int R, int ipw, int activation, int dbg = 0) {
+                                                    float *pool, int R, int ipw, int activation, int dbg = 0, int a16 = 0) {
   // dbg (MILE_CM_SKIP, timing experiments only -- results are wrong): 1 no full-size store, 2 no pooled store, 4 no MFMA loop, 8 no staging
   using G = CSlot<MODE>;
   constexpr int NMF = ((G::NS + 1) / 2 + 3) / 4;
@@ -264,7 +308,7 @@ __global__ __launch_bounds__(256) void k_conv5m_fwd(const float *in, long long s
     __syncthreads();
     if (!(dbg & 8) || b == b0) cm_stage_input<MODE>(cm_lds, in + (size_t)e * sE + (size_t)b * sB, sH, sW, sC, CIN, H, W, pad, tid);
     __syncthreads();
-    float *dst = out && !(dbg & 1) ? out + ((size_t)e * R + b) * npix * COUT : nullptr;
+    float *dst = out && !(dbg & 1) ? (a16 ? (float *)((uint16_t *)out + ((size_t)e * R + b) * npix * COUT) : out + ((size_t)e * R + b) * npix * COUT) : nullptr;
     float *pdst = pool + ((size_t)e * R + b) * Hq * Wq * COUT;
     if (dbg & 4) continue;
     cm_image_f<NMF>(cm_lds, ntiles, wave, so, ka,
@@ -279,7 +323,15 @@ __global__ __launch_bounds__(256) void k_conv5m_fwd(const float *in, long long s
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = act_fwd(activation, acc[i] + bias4[i]);
-        if (dst && y < Ho && x < Wo && 4 * g < COUT) {
+        if (dst && a16 && y < Ho && x < Wo && 4 * g < COUT) {          // ReLU: the backward pass needs only "was it positive"
+          uint16_t *o = (uint16_t *)dst + (size_t)(y * Wo + x) * COUT + 4 * g;
+          if constexpr (COUT % 4 == 0) {
+            *reinterpret_cast<cm_u32x2 *>(o) = cm_u32x2{cm_sign_pack2(v[0], v[1]), cm_sign_pack2(v[2], v[3])};
+          } else {
+            *reinterpret_cast<uint32_t *>(o) = cm_sign_pack2(v[0], v[1]);
+            if (4 * g + 2 < COUT) *reinterpret_cast<uint32_t *>(o + 2) = cm_sign_pack2(v[2], v[3]);
+          }
+        } else if (dst && y < Ho && x < Wo && 4 * g < COUT) {
           float *o = dst + (size_t)(y * Wo + x) * COUT + 4 * g;
           if constexpr (COUT % 4 == 0) {
             *reinterpret_cast<cm_f32x4 *>(o) = cm_f32x4{v[0], v[1], v[2], v[3]};
@@ -315,7 +367,7 @@ __global__ __launch_bounds__(256) void k_conv5m_fwd(const float *in, long long s
 template <int COUT>
 __global__ __launch_bounds__(256) void k_conv5m_fwd2x(const float *in, long long sE, long long sB, long long sH, long long sW, long long sC,
                                                       int CIN, int H, int W, int pad, const float *theta, int k_off, int b_off, int d, float *out,
-                                                      float *pool, int R, int ipw, int activation) {
+                                                      float *pool, int R, int ipw, int activation, int a16 = 0) {
   using G = CSlot<CM_IN4>;
   static_assert(2 * COUT <= 16 && COUT % 2 == 0, "rows = (channel, pixel of the pair)");
   constexpr int NMF = ((G::NS + 1) / 2 + 3) / 4;
@@ -343,7 +395,7 @@ __global__ __launch_bounds__(256) void k_conv5m_fwd2x(const float *in, long long
     __syncthreads();
     cm_stage_input<CM_IN4>(cm_lds, in + (size_t)e * sE + (size_t)b * sB, sH, sW, sC, CIN, H, W, pad, tid);
     __syncthreads();
-    float *dst = out ? out + ((size_t)e * R + b) * npix * COUT : nullptr;
+    float *dst = out ? (a16 ? (float *)((uint16_t *)out + ((size_t)e * R + b) * npix * COUT) : out + ((size_t)e * R + b) * npix * COUT) : nullptr;
     float *pdst = pool + ((size_t)e * R + b) * Hq * Wq * COUT;
     cm_image_f<NMF>(cm_lds, ntiles, wave, so, ka,
       [&](const int t) {
@@ -358,9 +410,15 @@ __global__ __launch_bounds__(256) void k_conv5m_fwd2x(const float *in, long long
         const float v0 = act_fwd(activation, acc[0] + bias0), v1 = act_fwd(activation, acc[1] + bias0);
         const float v2 = act_fwd(activation, acc[2] + bias1), v3 = act_fwd(activation, acc[3] + bias1);
         if (dst && rows_on && y < Ho) {
-          float *o = dst + (size_t)(y * Wo + x) * COUT + 2 * g;
-          if (x < Wo) *reinterpret_cast<cm_f32x2 *>(o) = cm_f32x2{v0, v2};
-          if (x + 1 < Wo) *reinterpret_cast<cm_f32x2 *>(o + COUT) = cm_f32x2{v1, v3};
+          if (a16) {                                   // ReLU: the backward pass needs only "was it positive"
+            uint16_t *o = (uint16_t *)dst + (size_t)(y * Wo + x) * COUT + 2 * g;
+            if (x < Wo) *reinterpret_cast<uint32_t *>(o) = cm_sign_pack2(v0, v2);
+            if (x + 1 < Wo) *reinterpret_cast<uint32_t *>(o + COUT) = cm_sign_pack2(v1, v3);
+          } else {
+            float *o = dst + (size_t)(y * Wo + x) * COUT + 2 * g;
+            if (x < Wo) *reinterpret_cast<cm_f32x2 *>(o) = cm_f32x2{v0, v2};
+            if (x + 1 < Wo) *reinterpret_cast<cm_f32x2 *>(o + COUT) = cm_f32x2{v1, v3};
+          }
         }
         const float h0 = v0 + v1, h1 = v2 + v3;        // window sum in the order of k_avgpool2: (a00 + a01) + (a10 + a11)
         const float s0 = 0.25f * (h0 + __shfl_xor(h0, 8)), s1 = 0.25f * (h1 + __shfl_xor(h1, 8));
@@ -374,8 +432,8 @@ __global__ __launch_bounds__(256) void k_conv5m_fwd2x(const float *in, long long
 // dz = unpool(dp) * act'(a): dz[y][x][c] = (avg-pool backward: dp[y/2][x/2][c] / 4, zero on the cropped border) * act'(a[y][x][c])
 // (mile_lenet.h dz_from_pool).  npix_alloc pixels are written (zeros outside the image).  One pixel per thread and pass, its
 // channels as 8- / 16-byte loads, U pixels' loads in flight (see cm_stage_input); a / dp rows are 8-byte aligned (COUT even).
-template <int COUT>
-__device__ __forceinline__ void cm_stage_dz(char *zt, const float *dp_img, const float *a_img, int Ho, int Wo, int halo, int npix_alloc,
+template <int COUT, bool A16 = false>
+__device__ __forceinline__ void cm_stage_dz(char *zt, const float *dp_img, const void *a_img, int Ho, int Wo, int halo, int npix_alloc,
                                             int activation, int tid) {
   static_assert(COUT % 2 == 0 && COUT <= 16, "channel pairs");
   constexpr int U = COUT > 8 ? 2 : 4, VW = COUT % 4 == 0 ? 4 : 2;   // 2 x 16 channels x (a, dp) = 64 registers in flight
@@ -391,19 +449,17 @@ __device__ __forceinline__ void cm_stage_dz(char *zt, const float *dp_img, const
       const int y = yy - halo, x = xx - halo;
       in[u] = px < npix_alloc && yy < Ht && y >= 0 && y < Ho && x >= 0 && x < Wo;
       const bool pin = in[u] && y < 2 * Hq && x < 2 * Wq;
-      const float *ap = a_img + (size_t)(in[u] ? y * Wo + x : 0) * COUT;
+      cm_load_act<COUT, A16>(a_img, (size_t)(in[u] ? y * Wo + x : 0), av[u]);
       const float *gp = dp_img + (size_t)(pin ? (y >> 1) * Wq + (x >> 1) : 0) * COUT;
 #pragma unroll
       for (int c = 0; c < COUT; c += VW) {
         if constexpr (VW == 4) {
-          const cm_f32x4 ta = *reinterpret_cast<const cm_f32x4 *>(ap + c);
           const cm_f32x4 tg = pin ? *reinterpret_cast<const cm_f32x4 *>(gp + c) : cm_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-          for (int k = 0; k < 4; ++k) { av[u][c + k] = ta[k]; gv[u][c + k] = tg[k]; }
+          for (int k = 0; k < 4; ++k) gv[u][c + k] = tg[k];
         } else {
-          const cm_f32x2 ta = *reinterpret_cast<const cm_f32x2 *>(ap + c);
           const cm_f32x2 tg = pin ? *reinterpret_cast<const cm_f32x2 *>(gp + c) : cm_f32x2{0.0f, 0.0f};
-          av[u][c] = ta[0]; av[u][c + 1] = ta[1]; gv[u][c] = tg[0]; gv[u][c + 1] = tg[1];
+          gv[u][c] = tg[0]; gv[u][c + 1] = tg[1];
         }
       }
     }
@@ -430,7 +486,7 @@ __device__ __forceinline__ void cm_stage_dz(char *zt, const float *dp_img, const
 // VALID 5x5 conv, gradient w.r.t. the input (as k_conv5_dx): din[e][b][yi][xi][ci] = sum_{kh,kw,co} dz[yi-kh][xi-kw][co] K[kh][kw][ci][co]
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void k_conv5m_dx(const float *dp, const float *a, int activation, const float *theta, int k_off, int d,
-                                                   float *din, int R, int Ho, int Wo, int ipw) {
+                                                   float *din, int R, int Ho, int Wo, int ipw, int a16 = 0) {
   using G = CSlot<CM_DZ16>;
   constexpr int NMF = ((G::NS + 1) / 2 + 3) / 4;
   static_assert(COUT <= 16 && CIN <= 16, "one slot quartet / one MFMA row block");
@@ -453,7 +509,8 @@ __global__ __launch_bounds__(256) void k_conv5m_dx(const float *dp, const float 
   for (int b = b0; b < b1; ++b) {
     const size_t img = (size_t)e * R + b;
     __syncthreads();
-    cm_stage_dz<COUT>(cm_lds, dp + img * (Ho / 2) * (Wo / 2) * COUT, a + img * Ho * Wo * COUT, Ho, Wo, 4, Ht * Wt, activation, tid);
+    if (a16) cm_stage_dz<COUT, true>(cm_lds, dp + img * (Ho / 2) * (Wo / 2) * COUT, (const uint16_t *)a + img * Ho * Wo * COUT, Ho, Wo, 4, Ht * Wt, activation, tid);
+    else cm_stage_dz<COUT>(cm_lds, dp + img * (Ho / 2) * (Wo / 2) * COUT, a + img * Ho * Wo * COUT, Ho, Wo, 4, Ht * Wt, activation, tid);
     __syncthreads();
     float *dst = din + img * npix * CIN;
     cm_image_f<NMF>(cm_lds, (npix + 15) / 16, wave, so, ka,
@@ -478,7 +535,7 @@ __global__ __launch_bounds__(256) void k_conv5m_dx(const float *dp, const float 
 // (input channel, which pixel): 12 of 16 rows useful for conv2's 6 input channels and 15 MFMAs per 32 pixels instead of 26.
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void k_conv5m_dx2x(const float *dp, const float *a, int activation, const float *theta, int k_off, int d,
-                                                     float *din, int R, int Ho, int Wo, int ipw) {
+                                                     float *din, int R, int Ho, int Wo, int ipw, int a16 = 0) {
   using G = CSlot<CM_DZ16P>;
   constexpr int NMF = ((G::NS + 1) / 2 + 3) / 4;
   static_assert(COUT <= 16 && 2 * CIN <= 16 && CIN % 2 == 0, "one slot quartet / rows = (channel, pixel of the pair)");
@@ -502,7 +559,8 @@ __global__ __launch_bounds__(256) void k_conv5m_dx2x(const float *dp, const floa
     const size_t img = (size_t)e * R + b;
     __syncthreads();
     // + 8 pixels of zero slack: the kw' = -1 slot of an odd-width image's last pair reads one pixel past the tile
-    cm_stage_dz<COUT>(cm_lds, dp + img * (Ho / 2) * (Wo / 2) * COUT, a + img * Ho * Wo * COUT, Ho, Wo, 4, Ht * Wt + 8, activation, tid);
+    if (a16) cm_stage_dz<COUT, true>(cm_lds, dp + img * (Ho / 2) * (Wo / 2) * COUT, (const uint16_t *)a + img * Ho * Wo * COUT, Ho, Wo, 4, Ht * Wt + 8, activation, tid);
+    else cm_stage_dz<COUT>(cm_lds, dp + img * (Ho / 2) * (Wo / 2) * COUT, a + img * Ho * Wo * COUT, Ho, Wo, 4, Ht * Wt + 8, activation, tid);
     __syncthreads();
     float *dst = din + img * npix * CIN;
     cm_image_f<NMF>(cm_lds, (npairs + 15) / 16, wave, so, ka,
@@ -528,7 +586,7 @@ __global__ __launch_bounds__(256) void k_conv5m_dx2x(const float *dp, const floa
 template <int MODE, int COUT>
 __global__ __launch_bounds__(256) void k_conv5m_dw(const float *in, long long sE, long long sB, long long sH, long long sW, long long sC, int CIN,
                                                    int H, int W, int pad, const float *dp, const float *a, int activation, float *part, int R,
-                                                   int ipw) {
+                                                   int ipw, int a16 = 0) {
   using G = CSlot<MODE>;
   constexpr int NMT = (G::NS + 3) / 4;            // accumulator tiles of 4 slots x 4 channels = 16 kernel rows
   static_assert(COUT <= 16, "one MFMA column block");
@@ -553,7 +611,8 @@ __global__ __launch_bounds__(256) void k_conv5m_dw(const float *in, long long sE
     const size_t img = (size_t)e * R + b;
     __syncthreads();
     cm_stage_input<MODE>(tile, in + (size_t)e * sE + (size_t)b * sB, sH, sW, sC, CIN, H, W, pad, tid);
-    cm_stage_dz<COUT>(zt, dp + img * (Ho / 2) * (Wo / 2) * COUT, a + img * npix * COUT, Ho, Wo, 0, npix32, activation, tid);
+    if (a16) cm_stage_dz<COUT, true>(zt, dp + img * (Ho / 2) * (Wo / 2) * COUT, (const uint16_t *)a + img * npix * COUT, Ho, Wo, 0, npix32, activation, tid);
+    else cm_stage_dz<COUT>(zt, dp + img * (Ho / 2) * (Wo / 2) * COUT, a + img * npix * COUT, Ho, Wo, 0, npix32, activation, tid);
     __syncthreads();
     // chunks of 32 pixels: ch = wave, wave + 4, ...  The fragments of the next group of four accumulator tiles -- or of the next
     // chunk's first group and its dZ fragment -- are in flight while the current group's MFMAs run (see cm_image_f).
@@ -641,8 +700,8 @@ __global__ __launch_bounds__(256) void k_conv5m_dw(const float *in, long long sE
 
 // dZ of one image as PAIR rows for the kernel-gradient pass: zt[pair (y, x / 2)][column 2 co + dxo] = dz[y][x + dxo][co], bf16,
 // npairs_alloc rows written (zeros outside the image).  One pair per thread and pass, U pairs' loads in flight.
-template <int COUT>
-__device__ __forceinline__ void cm_stage_dz_pairs(char *zt, const float *dp_img, const float *a_img, int Ho, int Wo, int npairs_alloc,
+template <int COUT, bool A16 = false>
+__device__ __forceinline__ void cm_stage_dz_pairs(char *zt, const float *dp_img, const void *a_img, int Ho, int Wo, int npairs_alloc,
                                                   int activation, int tid) {
   static_assert(COUT % 2 == 0 && 2 * COUT <= 16, "channel pairs, 16 columns");
   constexpr int U = 2;
@@ -659,13 +718,12 @@ __device__ __forceinline__ void cm_stage_dz_pairs(char *zt, const float *dp_img,
       for (int dxo = 0; dxo < 2; ++dxo) {
         in[u][dxo] = pi < npairs_alloc && y < Ho && x + dxo < Wo;
         const bool pin = in[u][dxo] && y < 2 * Hq && x + dxo < 2 * Wq;
-        const float *ap = a_img + (size_t)(in[u][dxo] ? y * Wo + x + dxo : 0) * COUT;
+        cm_load_act<COUT, A16>(a_img, (size_t)(in[u][dxo] ? y * Wo + x + dxo : 0), av[u][dxo]);
         const float *gp = dp_img + (size_t)(pin ? (y >> 1) * Wq + ((x + dxo) >> 1) : 0) * COUT;
 #pragma unroll
         for (int c = 0; c < COUT; c += 2) {
-          const cm_f32x2 ta = *reinterpret_cast<const cm_f32x2 *>(ap + c);
           const cm_f32x2 tg = pin ? *reinterpret_cast<const cm_f32x2 *>(gp + c) : cm_f32x2{0.0f, 0.0f};
-          av[u][dxo][c] = ta[0]; av[u][dxo][c + 1] = ta[1]; gv[u][dxo][c] = tg[0]; gv[u][dxo][c + 1] = tg[1];
+          gv[u][dxo][c] = tg[0]; gv[u][dxo][c + 1] = tg[1];
         }
       }
     }
@@ -696,7 +754,7 @@ __device__ __forceinline__ void cm_stage_dz_pairs(char *zt, const float *dp_img,
 template <int COUT>
 __global__ __launch_bounds__(256) void k_conv5m_dw2x(const float *in, long long sE, long long sB, long long sH, long long sW, long long sC,
                                                      int CIN, int H, int W, int pad, const float *dp, const float *a, int activation, float *part,
-                                                     int R, int ipw) {
+                                                     int R, int ipw, int a16 = 0) {
   using G = CSlot<CM_IN4>;
   constexpr int NMT = (G::NS + 3) / 4;            // 8 accumulator tiles of 4 slots x 4 channels
   static_assert(2 * COUT <= 16 && COUT % 2 == 0, "columns = (channel, pixel of the pair)");
@@ -721,7 +779,8 @@ __global__ __launch_bounds__(256) void k_conv5m_dw2x(const float *in, long long 
     const size_t img = (size_t)e * R + b;
     __syncthreads();
     cm_stage_input<CM_IN4>(tile, in + (size_t)e * sE + (size_t)b * sB, sH, sW, sC, CIN, H, W, pad, tid);
-    cm_stage_dz_pairs<COUT>(zt, dp + img * (Ho / 2) * (Wo / 2) * COUT, a + img * npix * COUT, Ho, Wo, npairs32, activation, tid);
+    if (a16) cm_stage_dz_pairs<COUT, true>(zt, dp + img * (Ho / 2) * (Wo / 2) * COUT, (const uint16_t *)a + img * npix * COUT, Ho, Wo, npairs32, activation, tid);
+    else cm_stage_dz_pairs<COUT>(zt, dp + img * (Ho / 2) * (Wo / 2) * COUT, a + img * npix * COUT, Ho, Wo, npairs32, activation, tid);
     __syncthreads();
     constexpr int NG = (NMT + 3) / 4;
     static_assert(NG % 2 == 0, "the register double buffer returns to buffer 0 at every chunk");
