@@ -1,6 +1,8 @@
-// LeNet target (BASELINE config 5, src/models/images/cnns.py:33-66): convolutions as im2col + the
-// strided-batched SGEMMs of the layer-wise path (mile_grad_gemm.h), pooling / col2im / im2col as the
-// elementwise HIP kernels below.  fp32, correctness-first: the im2col matrices live in HBM.
+// LeNet target (BASELINE config 5, src/models/images/cnns.py:33-66), fp32 (MILE_GRAD_LENET_F32, what AUTO takes): the
+// convolutions as hand-written direct kernels (k_conv5_fwd / k_conv5_dx / k_conv5_dw below: LDS image tiles, no im2col
+// matrices), the Dense layers as strided-batched SGEMMs (mile_grad_gemm.h), pooling as an elementwise kernel.  The first
+// implementation -- im2col + SGEMMs + col2im, the matrices in HBM -- is kept as second implementation / fallback for images too
+// large for the tiles (MILE_LENET_GEMM=1).  The bf16 MFMA form of the convolutions is mile_lenet_mfma.h.
 //   x NCHW -> Conv(6, 5x5, pad 2) -> act -> avg_pool 2 -> Conv(16, 5x5) -> act -> avg_pool 2
 //   -> flatten (h, w, c) -> Dense(120) -> act -> Dense(84) -> act -> Dense(out)
 // Activations are NHWC with particles folded into the batch: [E*R][H][W][C].

@@ -18,10 +18,11 @@
 // weights arrive pre-split (k_wide_prep_weights), so it is a few % of the MFMA time instead of half of it.
 // TERMS = 1 gives the bf16-operand form (one product, operands rounded to nearest-even) for callers that ask for it.
 //
-// Tiling: workgroup = 4 waves = one per SIMD, C tile 128 x 128, K chunk 64; wave (wm, wn) owns a 64 x 64 quadrant = 2 x 2
-// MFMA tiles (64 accumulator registers).  Operand tiles live in LDS as swizzled bf16 term images (mile_bf16_frag.h: one
-// layout serves row reads ds_read_b128 and transposed reads ds_read_b64_tr_b16, conflict-free), single-buffered: the next
-// chunk's global loads are issued before the 96 MFMAs of the current chunk and are split / stored behind them.
+// Tiling: workgroup = 4 waves, C tile 128 x 128, K chunk 32 (56-64 KB of LDS: TWO workgroups per CU, one's staging under the
+// other's MFMAs); wave (wm, wn) owns a 64 x 64 quadrant = 2 x 2 MFMA tiles (64 accumulator registers).  Operand tiles live in LDS
+// as swizzled bf16 term images (mile_bf16_frag.h: one layout serves row reads ds_read_b128 and transposed reads
+// ds_read_b64_tr_b16, conflict-free), single-buffered: the next chunk's global loads are issued before the 48 MFMAs of the
+// current chunk and are split / stored behind them.  Whole-tile shapes take a predicate-free instantiation (FULL).
 // grid = (N tiles, M tiles, batch): the batch (particle) index is slowest, so concurrently running workgroups share one
 // particle's weights in L2.
 #pragma once
@@ -616,28 +617,6 @@ __global__ __launch_bounds__(256) void k_wide_head(float *out, long long sOut, i
   if (tid == 0) {
     const float t = (red[0] + red[1]) + (red[2] + red[3]);
     llacc[e] = first_chunk ? t : llacc[e] + t;
-  }
-}
-
-// ---- bias gradient: column sums of dZ [E][R][ld] -> slab[e * dp + b_off + c] (+)= ---------------------------------------
-// workgroup = (64-column block, particle); a wave walks rows with one column per lane (256-byte coalesced reads).
-__global__ __launch_bounds__(256) void k_wide_colsum(const float *dZ, long long sZ, int ld, int R, int W, float *slab, long long dp, int b_off,
-                                                     int accumulate) {
-  __shared__ float red[4][64];
-  const int e = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
-  const float *z = dZ + (size_t)e * sZ;
-  float s0 = 0.0f, s1 = 0.0f;
-  if (c < W) {
-    int rr = w;
-    for (; rr + 4 < R; rr += 8) { s0 += z[(size_t)rr * ld + c]; s1 += z[(size_t)(rr + 4) * ld + c]; }
-    for (; rr < R; rr += 4) s0 += z[(size_t)rr * ld + c];
-  }
-  red[w][threadIdx.x & 63] = s0 + s1;
-  __syncthreads();
-  if (w == 0 && c < W) {
-    const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    float *o = slab + (size_t)e * dp + b_off + c;
-    *o = accumulate ? *o + t : t;
   }
 }
 
