@@ -54,7 +54,10 @@ def test_lenet_logpost_grad_matches_oracle(LN, C, H, W, K, act, task, prior, N, 
         assert _relerr(g[:, off:off + n], g_ref[:, off:off + n]) < 5e-5, name
 
 
-@pytest.mark.parametrize('C,H,W,K,act,task,prior,N,E', CASES + [(4, 20, 24, 4, 'relu', 'classification', 'Normal', 19, 2)])
+@pytest.mark.parametrize('C,H,W,K,act,task,prior,N,E', CASES + [
+    (4, 20, 24, 4, 'relu', 'classification', 'Normal', 19, 2),       # four input channels: a full slot
+    (3, 18, 22, 5, 'relu', 'classification', 'Normal', 7, 2),        # conv2's input is 9 x 11: odd width in the pair form of the input gradient
+])
 def test_lenet_mfma_convolutions_match_the_bf16_recipe(LN, C, H, W, K, act, task, prior, N, E):
     """`lenet_bf16`: the five convolution products as implicit GEMMs on v_mfma_f32_16x16x32_bf16 with bf16-rounded operands,
     against the oracle's restatement of that recipe (`logpost_and_grad_bf16`, fp64 accumulation).  The two round fp32- vs
