@@ -279,7 +279,9 @@ __device__ __forceinline__ void cm_image_f(const char *tile, int ntiles, int wav
 template <int MODE, int COUT>
 __global__ __launch_bounds__(256) void k_conv5m_fwd(const float *in, long long sE, long long sB, long long sH, long long sW, long long sC,
                                                     int CIN, int H, int W, int pad, const float *theta, int k_off, int b_off, int d, float *out,
-                                                    float *pool, int R, int ipw, int activation, int dbg = 0, int a16 = 0) {
+                                                    float *pool, int R, int ipw, int activation, int dbg = 0, int a16 = 0, int ni = 1) {
+  // ni images are staged per barrier pair (small images: conv2's 144 output pixels are 12 tiles -- three tiles per wave in two pair
+  // rounds; four images at once fill the rounds and quarter the barriers).
   // dbg (MILE_CM_SKIP, timing experiments only -- results are wrong): 1 no full-size store, 2 no pooled store, 4 no MFMA loop, 8 no staging
   using G = CSlot<MODE>;
   constexpr int NMF = ((G::NS + 1) / 2 + 3) / 4;
@@ -301,38 +303,46 @@ __global__ __launch_bounds__(256) void k_conv5m_fwd(const float *in, long long s
   float bias4[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) bias4[i] = 4 * g + i < COUT ? theta[(size_t)e * d + b_off + 4 * g + i] : 0.0f;
-  const float inv_tx = 1.0f / (float)TX;
+  const float inv_tx = 1.0f / (float)TX, inv_nt = 1.0f / (float)ntiles;
   const int dy = n16 >> 3, dx = n16 & 7;
+  const int tile_bytes = ((H + 2 * pad) * Wp + 8) * G::PB;              // one image's tile (a multiple of 16 bytes)
   const int b0 = blockIdx.x * ipw, b1 = min(R, b0 + ipw);
-  for (int b = b0; b < b1; ++b) {
+  for (int b = b0; b < b1; b += ni) {
+    const int nimg = min(ni, b1 - b);
     __syncthreads();
-    if (!(dbg & 8) || b == b0) cm_stage_input<MODE>(cm_lds, in + (size_t)e * sE + (size_t)b * sB, sH, sW, sC, CIN, H, W, pad, tid);
+    if (!(dbg & 8) || b == b0)
+      for (int im = 0; im < nimg; ++im)
+        cm_stage_input<MODE>(cm_lds + im * tile_bytes, in + (size_t)e * sE + (size_t)(b + im) * sB, sH, sW, sC, CIN, H, W, pad, tid);
     __syncthreads();
     float *dst = out && !(dbg & 1) ? (a16 ? (float *)((uint16_t *)out + ((size_t)e * R + b) * npix * COUT) : out + ((size_t)e * R + b) * npix * COUT) : nullptr;
     float *pdst = pool + ((size_t)e * R + b) * Hq * Wq * COUT;
     if (dbg & 4) continue;
-    cm_image_f<NMF>(cm_lds, ntiles, wave, so, ka,
-      [&](const int t) {
+    cm_image_f<NMF>(cm_lds, nimg * ntiles, wave, so, ka,
+      [&](const int tt) {
+        const int im = cm_div(tt, inv_nt), t = tt - im * ntiles;
         const int ty = cm_div(t, inv_tx), tx = t - ty * TX;
         const int y = min(2 * ty + dy, Ho - 1), x = min(8 * tx + dx, Wo - 1);
-        return (y * Wp + x) * G::PB;
+        return im * tile_bytes + (y * Wp + x) * G::PB;
       },
-      [&](const int t, const cm_f32x4 acc) {
+      [&](const int tt, const cm_f32x4 acc) {
+        const int im = cm_div(tt, inv_nt), t = tt - im * ntiles;
         const int ty = cm_div(t, inv_tx), tx = t - ty * TX;
         const int y = 2 * ty + dy, x = 8 * tx + dx;
+        float *dst_i = dst ? (a16 ? (float *)((uint16_t *)dst + (size_t)im * npix * COUT) : dst + (size_t)im * npix * COUT) : nullptr;
+        float *pdst_i = pdst + (size_t)im * Hq * Wq * COUT;
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = act_fwd(activation, acc[i] + bias4[i]);
-        if (dst && a16 && y < Ho && x < Wo && 4 * g < COUT) {          // ReLU: the backward pass needs only "was it positive"
-          uint16_t *o = (uint16_t *)dst + (size_t)(y * Wo + x) * COUT + 4 * g;
+        if (dst_i && a16 && y < Ho && x < Wo && 4 * g < COUT) {          // ReLU: the backward pass needs only "was it positive"
+          uint16_t *o = (uint16_t *)dst_i + (size_t)(y * Wo + x) * COUT + 4 * g;
           if constexpr (COUT % 4 == 0) {
             *reinterpret_cast<cm_u32x2 *>(o) = cm_u32x2{cm_sign_pack2(v[0], v[1]), cm_sign_pack2(v[2], v[3])};
           } else {
             *reinterpret_cast<uint32_t *>(o) = cm_sign_pack2(v[0], v[1]);
             if (4 * g + 2 < COUT) *reinterpret_cast<uint32_t *>(o + 2) = cm_sign_pack2(v[2], v[3]);
           }
-        } else if (dst && y < Ho && x < Wo && 4 * g < COUT) {
-          float *o = dst + (size_t)(y * Wo + x) * COUT + 4 * g;
+        } else if (dst_i && y < Ho && x < Wo && 4 * g < COUT) {
+          float *o = dst_i + (size_t)(y * Wo + x) * COUT + 4 * g;
           if constexpr (COUT % 4 == 0) {
             *reinterpret_cast<cm_f32x4 *>(o) = cm_f32x4{v[0], v[1], v[2], v[3]};
           } else {
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(256) void k_conv5m_fwd(const float *in, long long s
           s4[i] = 0.25f * (h2 + __shfl_xor(h2, 8));
         }
         if (!(dbg & 2) && dy == 0 && (dx & 1) == 0 && y < 2 * Hq && x < 2 * Wq && 4 * g < COUT) {
-          float *o = pdst + (size_t)((y >> 1) * Wq + (x >> 1)) * COUT + 4 * g;
+          float *o = pdst_i + (size_t)((y >> 1) * Wq + (x >> 1)) * COUT + 4 * g;
           if constexpr (COUT % 4 == 0) {
             *reinterpret_cast<cm_f32x4 *>(o) = cm_f32x4{s4[0], s4[1], s4[2], s4[3]};
           } else {
@@ -586,7 +596,9 @@ __global__ __launch_bounds__(256) void k_conv5m_dx2x(const float *dp, const floa
 template <int MODE, int COUT>
 __global__ __launch_bounds__(256) void k_conv5m_dw(const float *in, long long sE, long long sB, long long sH, long long sW, long long sC, int CIN,
                                                    int H, int W, int pad, const float *dp, const float *a, int activation, float *part, int R,
-                                                   int ipw, int a16 = 0) {
+                                                   int ipw, int a16 = 0, int ni = 1) {
+  // ni images per barrier pair, their pixels concatenated along the MFMA K index (conv2: 144 pixels = 4.5 chunks of 32 leave the four
+  // waves 2 / 1 / 1 / 1 chunks per image; four images = 18 chunks, 5 / 5 / 4 / 4)
   using G = CSlot<MODE>;
   constexpr int NMT = (G::NS + 3) / 4;            // accumulator tiles of 4 slots x 4 channels = 16 kernel rows
   static_assert(COUT <= 16, "one MFMA column block");
@@ -594,9 +606,9 @@ __global__ __launch_bounds__(256) void k_conv5m_dw(const float *in, long long sE
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e = blockIdx.y;
   const int n16 = lane & 15, g = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
   const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4, Hp = H + 2 * pad, Wp = W + 2 * pad, npix = Ho * Wo;
-  const int npix32 = (npix + 31) / 32 * 32;
-  char *tile = cm_lds;                                              // (Hp * Wp + 8) pixels of PB bytes
-  char *zt = cm_lds + ((size_t)(Hp * Wp + 8) * G::PB + 15) / 16 * 16;   // [npix32][16] bf16, zero beyond the image
+  const int tile_bytes = ((Hp * Wp + 8) * G::PB + 15) / 16 * 16;   // one image's input tile
+  char *tile = cm_lds;                                              // ni tiles
+  char *zt = cm_lds + (size_t)ni * tile_bytes;                      // [roundup32(ni * npix)][16] bf16, zero beyond the last image
   int so[NMT];
 #pragma unroll
   for (int mt = 0; mt < NMT; ++mt) so[mt] = 4 * mt + p4 < G::NS ? G::off(4 * mt + p4, Wp) : 0;
@@ -607,12 +619,17 @@ __global__ __launch_bounds__(256) void k_conv5m_dw(const float *in, long long sE
   const cm_u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
   const int b0 = blockIdx.x * ipw, b1 = min(R, b0 + ipw);
-  for (int b = b0; b < b1; ++b) {
-    const size_t img = (size_t)e * R + b;
+  const float inv_np = 1.0f / (float)npix;
+  for (int b = b0; b < b1; b += ni) {
+    const int nimg = min(ni, b1 - b), ntot = nimg * npix, ntot32 = (ntot + 31) / 32 * 32;
     __syncthreads();
-    cm_stage_input<MODE>(tile, in + (size_t)e * sE + (size_t)b * sB, sH, sW, sC, CIN, H, W, pad, tid);
-    if (a16) cm_stage_dz<COUT, true>(zt, dp + img * (Ho / 2) * (Wo / 2) * COUT, (const uint16_t *)a + img * npix * COUT, Ho, Wo, 0, npix32, activation, tid);
-    else cm_stage_dz<COUT>(zt, dp + img * (Ho / 2) * (Wo / 2) * COUT, a + img * npix * COUT, Ho, Wo, 0, npix32, activation, tid);
+    for (int im = 0; im < nimg; ++im) {
+      const size_t img = (size_t)e * R + b + im;
+      const int rows = im + 1 < nimg ? npix : npix + ntot32 - ntot;        // the last image also zeroes the rows up to the chunk boundary
+      cm_stage_input<MODE>(tile + im * tile_bytes, in + (size_t)e * sE + (size_t)(b + im) * sB, sH, sW, sC, CIN, H, W, pad, tid);
+      if (a16) cm_stage_dz<COUT, true>(zt + (size_t)im * npix * 32, dp + img * (Ho / 2) * (Wo / 2) * COUT, (const uint16_t *)a + img * npix * COUT, Ho, Wo, 0, rows, activation, tid);
+      else cm_stage_dz<COUT>(zt + (size_t)im * npix * 32, dp + img * (Ho / 2) * (Wo / 2) * COUT, a + img * npix * COUT, Ho, Wo, 0, rows, activation, tid);
+    }
     __syncthreads();
     // chunks of 32 pixels: ch = wave, wave + 4, ...  The fragments of the next group of four accumulator tiles -- or of the next
     // chunk's first group and its dZ fragment -- are in flight while the current group's MFMAs run (see cm_image_f).
@@ -622,9 +639,10 @@ __global__ __launch_bounds__(256) void k_conv5m_dw(const float *in, long long sE
     auto addr = [&](const int ch, int &bs0, int &bs1, int &zo0, int &zo1) {
       // this lane's two rows of the transposed reads: pixels P0 = 32 ch + 8 g + q and P0 + 4 (dZ rows beyond the image are zero)
       const int P0 = 32 * ch + 8 * g + q, P1 = P0 + 4;
-      const int c0 = min(P0, npix - 1), c1 = min(P1, npix - 1);
-      const int y0 = cm_div(c0, inv_wo), x0 = c0 - y0 * Wo, y1 = cm_div(c1, inv_wo), x1 = c1 - y1 * Wo;
-      bs0 = (y0 * Wp + x0) * G::PB; bs1 = (y1 * Wp + x1) * G::PB;
+      const int c0 = min(P0, ntot - 1), c1 = min(P1, ntot - 1);
+      const int i0 = cm_div(c0, inv_np), i1 = cm_div(c1, inv_np), r0 = c0 - i0 * npix, r1 = c1 - i1 * npix;
+      const int y0 = cm_div(r0, inv_wo), x0 = r0 - y0 * Wo, y1 = cm_div(r1, inv_wo), x1 = r1 - y1 * Wo;
+      bs0 = i0 * tile_bytes + (y0 * Wp + x0) * G::PB; bs1 = i1 * tile_bytes + (y1 * Wp + x1) * G::PB;
       zo0 = P0 * 32 + 8 * p4; zo1 = P1 * 32 + 8 * p4;
     };
     auto load_z = [&](const int zo0, const int zo1) {
@@ -643,14 +661,14 @@ __global__ __launch_bounds__(256) void k_conv5m_dw(const float *in, long long sE
       }
     };
     int ch = wave;
-    if (ch * 32 < npix) {
+    if (ch * 32 < ntot) {
       int bs0, bs1, zo0, zo1;
       addr(ch, bs0, bs1, zo0, zo1);
       bf16x8 bz = load_z(zo0, zo1);
       load_a(bs0, bs1, 0, a0[0], a1[0]);
       for (bool more = true; more;) {
         const int nch = ch + 4;
-        more = nch * 32 < npix;
+        more = nch * 32 < ntot;
         int nb0 = 0, nb1 = 0, nz0 = 0, nz1 = 0;
         if (more) addr(nch, nb0, nb1, nz0, nz1);
         bf16x8 bzn = bz;
@@ -868,9 +886,9 @@ __global__ __launch_bounds__(256) void k_conv5m_dw2x(const float *in, long long 
 }
 
 // LDS bytes of the three kernels for a geometry (host side)
-static inline size_t cm_lds_fwd(int mode, int H, int W, int pad, int CIN, int COUT) {
+static inline size_t cm_lds_fwd(int mode, int H, int W, int pad, int CIN, int COUT, int ni = 1) {
   const int pb = mode == CM_IN4 ? 8 : 16;
-  return std::max((size_t)((H + 2 * pad) * (W + 2 * pad) + 8) * pb, (size_t)25 * CIN * COUT * 4);
+  return std::max((size_t)ni * ((H + 2 * pad) * (W + 2 * pad) + 8) * pb, (size_t)25 * CIN * COUT * 4);
 }
 static inline size_t cm_lds_dx(int Ho, int Wo, int CIN, int COUT) { return std::max((size_t)(Ho + 8) * (Wo + 8) * 32, (size_t)25 * CIN * COUT * 4); }
 static inline size_t cm_lds_dx2x(int Ho, int Wo, int CIN, int COUT) {
@@ -882,10 +900,10 @@ static inline size_t cm_lds_dw2x(int H, int W, int pad) {
   const size_t red = (size_t)4 * (8 + 1) * 64 * 16;
   return tiles > red ? tiles : red;
 }
-static inline size_t cm_lds_dw(int mode, int H, int W, int pad) {
+static inline size_t cm_lds_dw(int mode, int H, int W, int pad, int ni = 1) {
   const int pb = mode == CM_IN4 ? 8 : 16, ns = mode == CM_IN4 ? 30 : 50;
   const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4;
-  const size_t tiles = ((size_t)((H + 2 * pad) * (W + 2 * pad) + 8) * pb + 15) / 16 * 16 + (size_t)((Ho * Wo + 31) / 32 * 32) * 32;
+  const size_t tiles = (size_t)ni * (((size_t)((H + 2 * pad) * (W + 2 * pad) + 8) * pb + 15) / 16 * 16) + (size_t)((ni * Ho * Wo + 31) / 32 * 32) * 32;
   const size_t red = (size_t)4 * ((ns + 3) / 4 + 1) * 64 * 16;
   return tiles > red ? tiles : red;
 }
