@@ -522,6 +522,30 @@ def test_bench_gpus_n_starts_n_ranks_without_a_launcher():
     assert r2.returncode != 0 and 'WORLD_SIZE=1' in r2.stderr
 
 
+def test_bench_workloads_name_every_baseline_config():
+    """bench.py's workloads against BASELINE.json's configs and the oracle's shapes: B2 the default, B3 / B4 / B5 bounded secondary
+    legs of the default run; the FLOP models the roofline fields are priced with against hand counts."""
+    import importlib.util, json
+    spec = importlib.util.spec_from_file_location('bench_mod', ROOT / 'bench.py')
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from oracle import mclmc_oracle as oracle
+    from oracle import lenet_oracle
+    assert bench.WORKLOAD == 'B2' and [n for n, _, _ in bench.SECONDARY] == ['B3', 'B4', 'B5']
+    assert len(json.loads((ROOT / 'BASELINE.json').read_text())['configs']) == 5
+    for name in ('B2', 'B3', 'B4'):
+        o, N, E = oracle.config_spec(name)
+        assert f'd={o.n_params}' in bench.WORKLOADS[name]['text'] and f'N={N}' in bench.WORKLOADS[name]['text']
+    assert bench.WORKLOADS['B2']['ensemble'] == 128 and bench.WORKLOADS['B3']['kernel'] == 'mfma_w128_bf16'
+    b5 = bench.WORKLOADS['B5']
+    ln = lenet_oracle.LeNetSpec(*b5['image'], b5['classes'])
+    assert f'd={ln.n_params}' in b5['text'] and b5['kernel'] == 'lenet_bf16' and b5['ensemble'] * 8 == 256
+    # fwd 2 N W + bwd 4 N W - 2 N W0 (no input gradient for the first layer)
+    assert bench.grad_flops_per_particle(5, (64, 64, 64, 2), 1052) == 1052 * (6 * (5 * 64 + 64 * 64 * 2 + 64 * 2) - 2 * 5 * 64)
+    m1, m2, md = 32 * 32 * 75 * 6, 12 * 12 * 150 * 16, 576 * 120 + 120 * 84 + 84 * 10
+    assert bench.lenet_grad_flops_per_particle(3, 32, 32, 10, 4000) == 4000 * (6 * (m1 + m2 + md) - 2 * m1)
+
+
 def test_airfoil_table_loads_with_reference_split():
     """The shipped data fixture behind experiments/mclmc_airfoil_b1/b2.yaml (data/README.md): 1503 x 6, z-scored
     including the target (tabular.py:146-147), 70 / 10 / 20 split -> N_train = 1052."""
