@@ -65,6 +65,7 @@ struct mile_sampler {
   // the pre-split weight term planes
   float *wide_ws = nullptr; size_t wide_ws_floats = 0; int wide_R = 0, wide_E = 0;
   void *wide_wt = nullptr; size_t wide_wt_bytes = 0;
+  float *wide_hb = nullptr; size_t wide_hb_floats = 0;   // k_wide_headblock's per-workgroup partial sums
   // timing of grad launches
   bool timing = false;
   std::vector<hipEvent_t> ev;
@@ -316,6 +317,7 @@ int32_t mile_destroy(mile_sampler *s) {
   if (s->gemm_ones) (void)hipFree(s->gemm_ones);
   if (s->wide_ws) (void)hipFree(s->wide_ws);
   if (s->wide_wt) (void)hipFree(s->wide_wt);
+  if (s->wide_hb) (void)hipFree(s->wide_hb);
   if (s->dbg_buf) (void)hipFree(s->dbg_buf);
   if (s->tune_info) (void)hipFree(s->tune_info);
   if (s->blas && g_rb.destroy) (void)g_rb.destroy(s->blas);
@@ -1156,10 +1158,25 @@ static int launch_grad_wide(mile_sampler *s, const GradParams &gp, int E, hipStr
   }
   float *slab = gp.slabs;        // S = 1: [E][dp]
   const long long dp = gp.dp;
+  // The last layer (K <= 8 outputs on a hidden width <= 256) as one pass over the last hidden activations -- forward, head, dH and
+  // dW of that layer in k_wide_headblock -- instead of four launches on 128-wide MFMA tiles (fp32-faithful form only: the
+  // bf16-operand recipe rounds this product's operands)
+  const bool headblock = TERMS == 3 && L >= 2 && ds.widths[L - 2] <= 256 && ds.widths[L - 1] <= WH_KMAX &&
+                         getenv("MILE_WIDE_NO_HEADBLOCK") == nullptr;
+  constexpr int HB_ROWS = 512;                      // rows per workgroup of k_wide_headblock
+  if (headblock) {
+    const size_t need = (size_t)E * ((R + HB_ROWS - 1) / HB_ROWS) * ((size_t)ds.widths[L - 2] * ds.widths[L - 1] + ds.widths[L - 1] + 1);
+    if (need > s->wide_hb_floats) {
+      if (s->wide_hb) (void)hipFree(s->wide_hb);
+      s->wide_hb = nullptr; s->wide_hb_floats = 0;
+      HIP_TRY(hipMalloc(&s->wide_hb, need * 4));
+      s->wide_hb_floats = need;
+    }
+  }
   for (int r0 = 0, chunk = 0; r0 < N; r0 += R, ++chunk) {
     const int Rc = std::min(R, N - r0);
     // ---- forward
-    for (int l = 0; l < L; ++l) {
+    for (int l = 0; l < L - (headblock ? 1 : 0); ++l) {
       MMParams p{};
       if (l == 0) { p.A = gp.Xp + (size_t)r0 * Fp; p.sA = 0; p.lda = Fp; }   // X zero-padded to Fp columns
       else { p.A = H[l - 1]; p.sA = (long long)R * wp[l - 1]; p.lda = wp[l - 1]; }
@@ -1172,11 +1189,24 @@ static int launch_grad_wide(mile_sampler *s, const GradParams &gp, int E, hipStr
       HIP_TRY(launch_mm3_fwd<TERMS>(p, E, st));
     }
     // ---- head: log-likelihood and d(out), in place
-    k_wide_head<<<E, 256, 0, st>>>(H[L - 1], (long long)R * wp[L - 1], wp[L - 1], gp.y, r0, Rc, ds.widths[L - 1], ds.task, gp.llpart, chunk == 0);
-    // ---- backward
     float *dz = H[L - 1];
-    int pp = 0;
-    for (int l = L - 1; l >= 0; --l) {
+    int pp = 0, ltop = L - 1;
+    if (headblock) {
+      const int Wl = ds.widths[L - 2], K = ds.widths[L - 1], nblk = (Rc + HB_ROWS - 1) / HB_ROWS;
+#define MILE_HB(K_, WF_) k_wide_headblock<K_, WF_><<<dim3(nblk, E), 256, 0, st>>>(H[L - 2], (long long)R * wp[L - 2], wp[L - 2], Wl, gp.theta, d, \
+      ds.w_off[L - 1], ds.b_off[L - 1], gp.y, r0, Rc, ds.task, ds.activation, tmp[0], (long long)R * wp[L - 2], wp[L - 2], s->wide_hb, HB_ROWS)
+#define MILE_HB_K(K_) case K_: if (Wl == 256) MILE_HB(K_, true); else MILE_HB(K_, false); break;
+      switch (K) { MILE_HB_K(1) MILE_HB_K(2) MILE_HB_K(3) MILE_HB_K(4) MILE_HB_K(5) MILE_HB_K(6) MILE_HB_K(7) MILE_HB_K(8) }
+#undef MILE_HB_K
+#undef MILE_HB
+      k_wide_headblock_reduce<<<dim3(8, E), 256, 0, st>>>(s->wide_hb, nblk, Wl * K, K, slab, dp, ds.w_off[L - 1], ds.b_off[L - 1], gp.llpart,
+                                                          chunk != 0);
+      dz = tmp[0]; pp = 1; ltop = L - 2;
+    } else {
+      k_wide_head<<<E, 256, 0, st>>>(H[L - 1], (long long)R * wp[L - 1], wp[L - 1], gp.y, r0, Rc, ds.widths[L - 1], ds.task, gp.llpart, chunk == 0);
+    }
+    // ---- backward
+    for (int l = ltop; l >= 0; --l) {
       {  // dW_l[in][out] (+)= in^T dz, straight into the slab at the kernel's offset
         MMParams p{};
         if (l == 0) { p.A = gp.Xp + (size_t)r0 * Fp; p.sA = 0; p.lda = Fp; }

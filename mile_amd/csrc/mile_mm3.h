@@ -620,6 +620,143 @@ __global__ __launch_bounds__(256) void k_wide_head(float *out, long long sOut, i
   }
 }
 
+// ---- the LAST layer in one pass over the last hidden activations (K <= 8 outputs, hidden width W <= 256) ---------------------
+// Per row: out = H W + b in fp32 FMAs (a wave takes a row, a lane four of its columns, DPP butterfly sums), log-likelihood and
+// d(out) exactly as k_wide_head, dZ = (d(out) W^T) * act'(H) for the layer below written at once, and the row's contribution to
+// the weight / bias gradient accumulated in registers (a lane: its four columns x K).  Replaces four launches per row chunk --
+// the K-wide forward GEMM, k_wide_head, the K-wide dH and dW GEMMs -- which stream a rows x W activation through 128-wide MFMA
+// tiles for ~3 % of a B4 gradient's FLOPs (43 of 283 ms).  part[(e * nblk + blk) * (W K + K + 1)]: dW [W][K], db [K], ll;
+// k_wide_headblock_reduce sums the blocks in fixed order (deterministic).
+// K and "W == 256" are template parameters: with run-time bounds every class / column test became a branch in the row loop
+// (~700 instructions per row, most of them control flow); the loop is now straight-line code.
+#define WH_KMAX 8
+template <int K, bool WFULL>
+__global__ __launch_bounds__(256) void k_wide_headblock(const float *H, long long sH, int ldh, int W, const float *theta, long long d, int w_off,
+                                                        int b_off, const void *y, long long r0, int R, int task, int act, float *dZ,
+                                                        long long sZ, int ldz, float *part, int rows_per_wg) {
+  static_assert(K >= 1 && K <= WH_KMAX, "outputs");
+  __shared__ float red[4][256 * WH_KMAX];
+  __shared__ float redb[4][WH_KMAX + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e = blockIdx.y, blk = blockIdx.x;
+  const float *Hh = H + (size_t)e * sH;
+  float *dz = dZ + (size_t)e * sZ;
+  const float *Wk = theta + (size_t)e * d + w_off, *bk = theta + (size_t)e * d + b_off;
+  float w[4][K], gW[4][K], gb[K], bias[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    bias[k] = bk[k];
+    gb[k] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = lane + 64 * j;
+      w[j][k] = (WFULL || c < W) ? Wk[(size_t)c * K + k] : 0.0f;
+      gW[j][k] = 0.0f;
+    }
+  }
+  float ll = 0.0f;
+  const int rbeg = blk * rows_per_wg, rend = min(R, rbeg + rows_per_wg);
+  float hn[4];
+  auto load_row = [&](const int r, float (&h)[4]) {   // beyond the block: the last row again (never used)
+    const size_t ro = (size_t)min(r, rend - 1) * ldh;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = lane + 64 * j;
+      h[j] = (WFULL || c < W) ? Hh[ro + c] : 0.0f;
+    }
+  };
+  load_row(rbeg + wave, hn);
+  for (int r = rbeg + wave; r < rend; r += 4) {
+    float h[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = hn[j];
+    load_row(r + 4, hn);                                    // next row of this wave in flight
+    // out[k] is wave-uniform after the sum; class k's logit goes to LANE k of `o`, so that the softmax costs two expf per row and
+    // wave instead of two per class (uniform values still execute on the vector ALU: 14 redundant expf were most of this kernel)
+    float out01[2] = {0.0f, 0.0f};
+    int o_bits = __float_as_int(-INFINITY);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float t = h[0] * w[0][k];
+#pragma unroll
+      for (int j = 1; j < 4; ++j) t = fmaf(h[j], w[j][k], t);
+      const float tot = wave_sum(t) + bias[k];
+      if (k < 2) out01[k] = tot;
+      o_bits = lane == k ? __float_as_int(tot) : o_bits;   // (lane == k) is loop-invariant: one v_cndmask per class
+    }
+    const float o = __int_as_float(o_bits);
+    float dout[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) dout[k] = 0.0f;
+    if (task == MILE_TASK_REGRESSION) {
+      float dmu, ds;
+      ll += row_loss_regr(out01[0], out01[1], ((const float *)y)[r0 + r], dmu, ds);
+      dout[0] = dmu;
+      if constexpr (K > 1) dout[1] = ds;
+    } else {
+      const int yi = __builtin_amdgcn_readfirstlane(((const int32_t *)y)[r0 + r]);
+      auto first8 = [](float v, auto op) {                  // op-reduction over lanes 0..7, result read from lane 0 (uniform)
+        v = op(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)));    // quad_perm [1,0,3,2]
+        v = op(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false)));    // quad_perm [2,3,0,1]
+        v = op(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false)));   // row_half_mirror
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+      };
+      const float m = first8(o, [](float a, float b) { return fmaxf(a, b); });                 // lanes >= K hold -inf
+      const float se = first8(lane < K ? expf(o - m) : 0.0f, [](float a, float b) { return a + b; });
+      const float lse = m + logf(se);
+      const float l1 = __int_as_float(__builtin_amdgcn_readlane(o_bits, yi)) - lse;
+      const bool bad = isnan(l1);
+      const float dl = (bad || lane >= K) ? 0.0f : ((lane == yi ? 1.0f : 0.0f) - expf(o - lse));
+#pragma unroll
+      for (int k = 0; k < K; ++k) dout[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl), k));
+      ll += bad ? 0.0f : l1;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) gb[k] += dout[k];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = lane + 64 * j;
+      float t = 0.0f;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        t = fmaf(dout[k], w[j][k], t);
+        gW[j][k] = fmaf(h[j], dout[k], gW[j][k]);
+      }
+      if (WFULL || c < W) dz[(size_t)r * ldz + c] = t * act_bwd(act, h[j]);
+    }
+  }
+  // the four waves' sums (each over its rows) -> one, through LDS, fixed order
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[wave][(lane + 64 * j) * WH_KMAX + k] = gW[j][k];
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) redb[wave][k] = gb[k];
+    redb[wave][WH_KMAX] = ll;
+  }
+  __syncthreads();
+  float *dst = part + ((size_t)e * gridDim.x + blk) * ((size_t)W * K + K + 1);
+  for (int i = tid; i < W * K; i += 256) {
+    const int c = i / K, k = i - c * K;
+    dst[i] = (red[0][c * WH_KMAX + k] + red[1][c * WH_KMAX + k]) + (red[2][c * WH_KMAX + k] + red[3][c * WH_KMAX + k]);
+  }
+  if (tid <= K) {
+    const int k = tid < K ? tid : WH_KMAX;
+    dst[W * K + tid] = (redb[0][k] + redb[1][k]) + (redb[2][k] + redb[3][k]);
+  }
+}
+// slab[e][w_off + i] (+)= sum_blk part, slab[e][b_off + k] (+)=, llacc[e] (=|+=)
+__global__ __launch_bounds__(256) void k_wide_headblock_reduce(const float *part, int nblk, int WK, int K, float *slab, long long dp, int w_off,
+                                                               int b_off, float *llacc, int accumulate) {
+  const int e = blockIdx.y, per = WK + K + 1;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < per; i += gridDim.x * 256) {
+    float s = 0.0f;
+    for (int b = 0; b < nblk; ++b) s += part[((size_t)e * nblk + b) * per + i];
+    float *o = i < WK ? slab + (size_t)e * dp + w_off + i : (i < WK + K ? slab + (size_t)e * dp + b_off + (i - WK) : llacc + e);
+    *o = accumulate ? *o + s : s;
+  }
+}
+
 // ---- evaluation: per-row log-likelihood of the head outputs out [S][R][ld] -> out_ll[(s0 + s) * N + r0 + r] ------------
 // (no nansum zeroing: src/inference/metrics.py:247-294 uses the distributions' log_prob directly)
 __global__ __launch_bounds__(256) void k_wide_rowll(const float *out, long long sOut, int ld, const void *y, long long r0, int R, int K, int task,
