@@ -954,7 +954,7 @@ static hipError_t launch_mm3_k(const MMParams &p, int batch, hipStream_t st) {
   static const bool dbg = getenv("MILE_DEBUG") && (atoi(getenv("MILE_DEBUG")) & 64);
   if constexpr (!FULL) {   // whole tiles everywhere: the predicate-free instantiation (timing stamps need the general one)
     static const bool no_full = getenv("MILE_MM_NO_FULL") != nullptr;
-    if (!dbg && !no_full && p.M % 128 == 0 && p.N % 128 == 0 && p.K % KC == 0)
+    if (!dbg && !no_full && p.M % 128 == 0 && p.N % 128 == 0)
       return launch_mm3_k<ALAY, BSRC, EPI, TERMS, ACT, ACCUM, COLSUM, true>(p, batch, st);
   }
   static bool attr_set = false;

@@ -127,9 +127,10 @@ struct MMLayout {
 // ACT (MILE_ACT_* or -1 = none) and ACCUM are template parameters: the epilogue's 64 elements per lane run branch-free
 // (as a per-element run-time switch the epilogue was most of the kernel's instructions; dispatched inside the kernel its
 // eight inlined copies spilled 150 registers).
-// FULL: M and N are multiples of 128 and K of KC (the hidden layers of B4 at every chunk size the host picks): no tile / row /
-// column / ragged-chunk predicates and no timing stamps -- the K loop is one basic block the scheduler can order freely
-// (the general form carries ~3 SALU instructions per MFMA and a branch around every MFMA group).
+// FULL: M and N are multiples of 128 (the 256-wide layers of B4 at every chunk size the host picks; any K -- a ragged last chunk
+// costs two wave-uniform tests): no tile / row / column predicates and no timing stamps -- the MFMA groups of the K loop are one
+// basic block the scheduler can order freely (the general form carries ~3 SALU instructions per MFMA and a branch around every
+// MFMA group).
 template <int ALAY, int BSRC, int EPI, int TERMS, int KC, int ACT, bool ACCUM, bool COLSUM = false, bool FULL = false>
 __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
   using LY = MMLayout<ALAY, BSRC, TERMS, KC>;
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
   }
   auto load_a = [&](const int st, const int k0) {
     const int so = ALAY == MM_A_MK ? k0 * 4 : k0 * p.lda * 4;
-    const bool ragged = !FULL && k0 + KC > K;
+    const bool ragged = k0 + KC > K;
 #pragma unroll
     for (int i = 0; i < A_NP; ++i) {
       int vo = voa[i];
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
     }
   }
   auto load_b = [&](const int st, const int k0) {
-    const bool ragged = !FULL && k0 + KC > K;
+    const bool ragged = k0 + KC > K;
     if constexpr (BSRC == MM_B_F32_KN) {
       const int so = k0 * p.ldb * 4;
 #pragma unroll
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
       load_a(j, KC * (kc + PF));
       load_b(j, KC * (kc + PF));
     }
-    const int ksteps = FULL ? KC / 16 : min(KC / 16, (K - KC * kc + 15) / 16);
+    const int ksteps = min(KC / 16, (K - KC * kc + 15) / 16);
     auto kstep = [&](const int ks) {
       bf16x8 af[2][TERMS], bfr[2][TERMS];
 #pragma unroll
