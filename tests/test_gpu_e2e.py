@@ -710,9 +710,17 @@ def test_full_size_properties_b4(oracle):
     perm = torch.randperm(E, generator=torch.Generator().manual_seed(2))
     lp3, g3 = ge.logpost_grad(th[perm])
     assert _rel(lp3.cpu(), lp1.cpu()[perm]) < 1e-6 and _rel(g3.cpu(), g1.cpu()[perm]) < 1e-6
-    # the single-launch generic kernel on 3 particles and the first 3000 rows
-    sub = slice(0, 3000)
-    r2 = _engine(ospec, prob['X'][sub], prob['y'][sub], 'generic').logpost_grad(th[:3])
+    # the single-launch generic kernel on 3 particles and the first 3000 rows.  Rows with a pre-activation within fp32 rounding
+    # of the ReLU kink are left out for all three kernels (as in test_logpost_grad_matches_oracle): the kernels sum in different
+    # orders, and a unit that is +1e-8 in one and -1e-8 in another flips ReLU' for its row (4e-3 absolute on a bias gradient)
+    Xs, ys = prob['X'][:3000], prob['y'][:3000]
+    _, zs, _ = oracle.mlp_forward(ospec, prob['theta0'][:3].astype(np.float64), Xs, keep=True)
+    near = np.zeros(len(Xs), dtype=bool)
+    for z in zs[:-1]:
+        near |= (np.abs(z) < 3e-7 * np.abs(z).max()).any(axis=(0, 2))
+    assert near.sum() < 30, near.sum()
+    Xs, ys = np.ascontiguousarray(Xs[~near]), np.ascontiguousarray(ys[~near])
+    r2 = _engine(ospec, Xs, ys, 'generic').logpost_grad(th[:3])
     for k in ('mfma_wide_bf16x3', 'gemm_f32'):          # the MFMA GEMMs, and the rocBLAS cross-check
-        r1 = _engine(ospec, prob['X'][sub], prob['y'][sub], k).logpost_grad(th[:3])
+        r1 = _engine(ospec, Xs, ys, k).logpost_grad(th[:3])
         assert _rel(r1[0].cpu(), r2[0].cpu()) < 2e-6 and _rel(r1[1].cpu(), r2[1].cpu()) < 2e-5, k
