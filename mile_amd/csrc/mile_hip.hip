@@ -655,17 +655,19 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
   const int geo = (g.C == 3 && g.H == 32 && g.W == 32) ? 1 : (g.C == 1 && g.H == 28 && g.W == 28) ? 3 : 0;
   const bool direct = getenv("MILE_LENET_GEMM") == nullptr && g.C <= 16 && lds_max <= 150 * 1024;
   // MILE_GRAD_LENET_BF16: the five convolution launches on the bf16 matrix pipe (mile_lenet_mfma.h), everything else as below
-  // conv2's images are small: several per barrier pair (as many as keep the tiles under ~40 KB, at most 4)
+  // small images: several per barrier pair (as many as keep the tiles under ~56 KB, at most 4)
   const size_t per_img2 = (size_t)(g.hp1 * g.wp1 + 8) * 16 + (size_t)g.h2 * g.w2 * 32;   // input tile + dZ rows of one image
-  const int ni2 = getenv("MILE_CM_NI") ? std::max(1, std::min(8, atoi(getenv("MILE_CM_NI")))) : std::max(1, std::min(4, (int)(40960 / per_img2)));
+  const int ni2 = getenv("MILE_CM_NI") ? std::max(1, std::min(8, atoi(getenv("MILE_CM_NI")))) : std::max(1, std::min(4, (int)(57344 / per_img2)));
   const size_t ldm_f1 = cm_lds_fwd(CM_IN4, g.H, g.W, 2, g.C, 6), ldm_f2 = cm_lds_fwd(CM_IN8, g.hp1, g.wp1, 0, 6, 16, ni2), ldm_x2 = cm_lds_dx(g.h2, g.w2, 6, 16);
   const size_t ldm_w1 = cm_lds_dw(CM_IN4, g.H, g.W, 2), ldm_w2 = cm_lds_dw(CM_IN8, g.hp1, g.wp1, 0, ni2);
   // the 6-channel sides of the two convolutions in the PAIR forms (two pixels per MFMA row / column); MILE_CM_NO_PAIR: the pixel forms
   const bool pair = mfma && getenv("MILE_CM_NO_PAIR") == nullptr;
   // ReLU: the full-size conv activations are kept for the backward pass only as two-byte "was it positive" values
   const int a16 = mfma && act == MILE_ACT_RELU && getenv("MILE_CM_A32") == nullptr;
-  const size_t ldm_x2p = cm_lds_dx2x(g.h2, g.w2, 6, 16), ldm_w1p = cm_lds_dw2x(g.H, g.W, 2);
-  if (mfma && (!direct || g.C > 4 || std::max({ldm_f1, ldm_f2, ldm_x2, ldm_w1, ldm_w2, ldm_x2p, ldm_w1p}) > 150 * 1024))
+  const auto ni_for = [](size_t per_img) { return getenv("MILE_CM_NI") ? std::max(1, std::min(8, atoi(getenv("MILE_CM_NI")))) : std::max(1, std::min(4, (int)(57344 / per_img))); };
+  const int ni_x2 = ni_for((size_t)((g.h2 + 8) * (g.w2 + 8) + 8) * 32), ni_f1 = ni_for((size_t)((g.H + 4) * (g.W + 4) + 8) * 8);
+  const size_t ldm_x2p = cm_lds_dx2x(g.h2, g.w2, 6, 16, ni_x2), ldm_w1p = cm_lds_dw2x(g.H, g.W, 2), ldm_f1p = cm_lds_fwd(CM_IN4, g.H, g.W, 2, g.C, 6, ni_f1);
+  if (mfma && (!direct || g.C > 4 || std::max({ldm_f1, ldm_f2, ldm_x2, ldm_w1, ldm_w2, ldm_x2p, ldm_w1p, ldm_f1p}) > 150 * 1024))
     return fail(MILE_ERR_INVALID, "LENET_BF16 needs <= 4 image channels and an image that fits the LDS tiles");
   // Dense activations: exact widths on the rocBLAS path; k_mm3 wants rows of 8 k floats (zero padding columns)
   const size_t w_f2 = mfma ? 88 : 84, w_out = mfma ? (size_t)(g.K + 7) / 8 * 8 : (size_t)g.K;
@@ -748,7 +750,7 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
 #define LAUNCH_FWD1(GEO_) k_conv5_fwd<6, GEO_><<<dim3(nwg, E), 256, lds_f1, st>>>(Xc, 0, (long long)g.C * HW, g.W, 1, (long long)HW, g.C, g.H, g.W, 2, theta, g.k_c1, g.b_c1, d, a1, (int)Rc, ipw, act)
 #define LAUNCH_FWD2(GEO_) k_conv5_fwd<16, GEO_><<<dim3(nwg, E), 256, lds_f2, st>>>(p1, Rc * (long long)n_p1, (long long)n_p1, g.wp1 * 6, 6, 1, 6, g.hp1, g.wp1, 0, theta, g.k_c2, g.b_c2, d, a2, (int)Rc, ipw, act)
       // MFMA form: the pooled activations come out of the convolution's own epilogue; evaluation skips the full-size ones
-      if (pair) k_conv5m_fwd2x<6><<<dim3(nwg, E), 256, ldm_f1, st>>>(Xc, 0, (long long)g.C * HW, g.W, 1, (long long)HW, g.C, g.H, g.W, 2, theta, g.k_c1, g.b_c1, d, grad ? a1 : nullptr, p1, (int)Rc, ipw, act, a16);
+      if (pair) k_conv5m_fwd2x<6><<<dim3(nwg, E), 256, ldm_f1p, st>>>(Xc, 0, (long long)g.C * HW, g.W, 1, (long long)HW, g.C, g.H, g.W, 2, theta, g.k_c1, g.b_c1, d, grad ? a1 : nullptr, p1, (int)Rc, ipw, act, a16, ni_f1);
       else if (mfma) k_conv5m_fwd<CM_IN4, 6><<<dim3(nwg, E), 256, ldm_f1, st>>>(Xc, 0, (long long)g.C * HW, g.W, 1, (long long)HW, g.C, g.H, g.W, 2, theta, g.k_c1, g.b_c1, d, grad ? a1 : nullptr, p1, (int)Rc, ipw, act, cm_dbg, a16);
       else if (geo == 1) LAUNCH_FWD1(1); else if (geo == 3) LAUNCH_FWD1(3); else LAUNCH_FWD1(0);
       if (!mfma) k_avgpool2<<<blocks(B * (long long)n_p1), 256, 0, st>>>(a1, p1, B, g.H, g.W, 6);
@@ -821,7 +823,7 @@ static int run_lenet(mile_sampler *s, const float *theta, int E, const float *X,
       if (mfma) k_conv5m_dw<CM_IN8, 16><<<dim3(nwg, E), 256, ldm_w2, st>>>(p1, Rc * (long long)n_p1, (long long)n_p1, g.wp1 * 6, 6, 1, 6, g.hp1, g.wp1, 0, dp2, a2, act, part2, (int)Rc, ipw, a16, ni2);
       else if (geo == 1) LAUNCH_DW2(2); else if (geo == 3) LAUNCH_DW2(4); else LAUNCH_DW2(0);
       k_conv_reduce<<<dim3(10, E), 256, 0, st>>>(part2, (int)nwg, 2400, 16, slab, dp, g.k_c2, g.b_c2, acc);
-      if (pair) k_conv5m_dx2x<6, 16><<<dim3(nwg, E), 256, ldm_x2p, st>>>(dp2, a2, act, theta, g.k_c2, d, dp1, (int)Rc, g.h2, g.w2, ipw, a16);
+      if (pair) k_conv5m_dx2x<6, 16><<<dim3(nwg, E), 256, ldm_x2p, st>>>(dp2, a2, act, theta, g.k_c2, d, dp1, (int)Rc, g.h2, g.w2, ipw, a16, ni_x2);
       else if (mfma) k_conv5m_dx<6, 16><<<dim3(nwg, E), 256, ldm_x2, st>>>(dp2, a2, act, theta, g.k_c2, d, dp1, (int)Rc, g.h2, g.w2, ipw, a16);
       else if (geo == 1) LAUNCH_DX(12, 12); else if (geo == 3) LAUNCH_DX(10, 10); else LAUNCH_DX(0, 0);
       if (pair) k_conv5m_dw2x<6><<<dim3(nwg, E), 256, ldm_w1p, st>>>(Xc, 0, (long long)g.C * HW, g.W, 1, (long long)HW, g.C, g.H, g.W, 2, dp1, a1, act, part1, (int)Rc, ipw, a16);

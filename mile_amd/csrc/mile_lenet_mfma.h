@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void k_conv5m_fwd(const float *in, long long s
 template <int COUT>
 __global__ __launch_bounds__(256) void k_conv5m_fwd2x(const float *in, long long sE, long long sB, long long sH, long long sW, long long sC,
                                                       int CIN, int H, int W, int pad, const float *theta, int k_off, int b_off, int d, float *out,
-                                                      float *pool, int R, int ipw, int activation, int a16 = 0) {
+                                                      float *pool, int R, int ipw, int activation, int a16 = 0, int ni = 1) {
   using G = CSlot<CM_IN4>;
   static_assert(2 * COUT <= 16 && COUT % 2 == 0, "rows = (channel, pixel of the pair)");
   constexpr int NMF = ((G::NS + 1) / 2 + 3) / 4;
@@ -398,24 +398,31 @@ __global__ __launch_bounds__(256) void k_conv5m_fwd2x(const float *in, long long
     }
   const bool rows_on = 2 * g < COUT;                 // this lane's rows are channels 2 g, 2 g + 1
   const float bias0 = rows_on ? theta[(size_t)e * d + b_off + 2 * g] : 0.0f, bias1 = rows_on ? theta[(size_t)e * d + b_off + 2 * g + 1] : 0.0f;
-  const float inv_tx = 1.0f / (float)TX;
+  const float inv_tx = 1.0f / (float)TX, inv_nt = 1.0f / (float)ntiles;
   const int dy = n16 >> 3, px = n16 & 7;
+  const int tile_bytes = ((H + 2 * pad) * Wp + 8) * G::PB;               // per image (ni images per barrier pair)
   const int b0 = blockIdx.x * ipw, b1 = min(R, b0 + ipw);
-  for (int b = b0; b < b1; ++b) {
+  for (int b = b0; b < b1; b += ni) {
+    const int nimg = min(ni, b1 - b);
     __syncthreads();
-    cm_stage_input<CM_IN4>(cm_lds, in + (size_t)e * sE + (size_t)b * sB, sH, sW, sC, CIN, H, W, pad, tid);
+    for (int im = 0; im < nimg; ++im)
+      cm_stage_input<CM_IN4>(cm_lds + im * tile_bytes, in + (size_t)e * sE + (size_t)(b + im) * sB, sH, sW, sC, CIN, H, W, pad, tid);
     __syncthreads();
-    float *dst = out ? (a16 ? (float *)((uint16_t *)out + ((size_t)e * R + b) * npix * COUT) : out + ((size_t)e * R + b) * npix * COUT) : nullptr;
-    float *pdst = pool + ((size_t)e * R + b) * Hq * Wq * COUT;
-    cm_image_f<NMF>(cm_lds, ntiles, wave, so, ka,
-      [&](const int t) {
+    float *dst0 = out ? (a16 ? (float *)((uint16_t *)out + ((size_t)e * R + b) * npix * COUT) : out + ((size_t)e * R + b) * npix * COUT) : nullptr;
+    float *pdst0 = pool + ((size_t)e * R + b) * Hq * Wq * COUT;
+    cm_image_f<NMF>(cm_lds, nimg * ntiles, wave, so, ka,
+      [&](const int tt) {
+        const int im = cm_div(tt, inv_nt), t = tt - im * ntiles;
         const int ty = cm_div(t, inv_tx), tx = t - ty * TX;
         const int y = min(2 * ty + dy, Ho - 1), x = min(16 * tx + 2 * px, Wo - 1);
-        return (y * Wp + x) * G::PB;
+        return im * tile_bytes + (y * Wp + x) * G::PB;
       },
-      [&](const int t, const cm_f32x4 acc) {
+      [&](const int tt, const cm_f32x4 acc) {
+        const int im = cm_div(tt, inv_nt), t = tt - im * ntiles;
         const int ty = cm_div(t, inv_tx), tx = t - ty * TX;
         const int y = 2 * ty + dy, x = 16 * tx + 2 * px;
+        float *dst = dst0 ? (a16 ? (float *)((uint16_t *)dst0 + (size_t)im * npix * COUT) : dst0 + (size_t)im * npix * COUT) : nullptr;
+        float *pdst = pdst0 + (size_t)im * Hq * Wq * COUT;
         // registers: 0 = (channel 2g, x), 1 = (2g, x + 1), 2 = (2g + 1, x), 3 = (2g + 1, x + 1)
         const float v0 = act_fwd(activation, acc[0] + bias0), v1 = act_fwd(activation, acc[1] + bias0);
         const float v2 = act_fwd(activation, acc[2] + bias1), v3 = act_fwd(activation, acc[3] + bias1);
@@ -545,7 +552,7 @@ __global__ __launch_bounds__(256) void k_conv5m_dx(const float *dp, const float 
 // (input channel, which pixel): 12 of 16 rows useful for conv2's 6 input channels and 15 MFMAs per 32 pixels instead of 26.
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void k_conv5m_dx2x(const float *dp, const float *a, int activation, const float *theta, int k_off, int d,
-                                                     float *din, int R, int Ho, int Wo, int ipw, int a16 = 0) {
+                                                     float *din, int R, int Ho, int Wo, int ipw, int a16 = 0, int ni = 1) {
   using G = CSlot<CM_DZ16P>;
   constexpr int NMF = ((G::NS + 1) / 2 + 3) / 4;
   static_assert(COUT <= 16 && 2 * CIN <= 16 && CIN % 2 == 0, "one slot quartet / rows = (channel, pixel of the pair)");
@@ -564,24 +571,32 @@ __global__ __launch_bounds__(256) void k_conv5m_dx2x(const float *dp, const floa
       so[c][u] = s < G::NS ? G::off(s, Wt) : 0;
     }
   const float inv_w2 = 1.0f / (float)W2;
+  const int ntiles = (npairs + 15) / 16, tile_bytes = (Ht * Wt + 8) * 32;     // per image (ni images per barrier pair)
+  const float inv_nt = 1.0f / (float)ntiles;
   const int b0 = blockIdx.x * ipw, b1 = min(R, b0 + ipw);
-  for (int b = b0; b < b1; ++b) {
-    const size_t img = (size_t)e * R + b;
+  for (int b = b0; b < b1; b += ni) {
+    const int nimg = min(ni, b1 - b);
     __syncthreads();
-    // + 8 pixels of zero slack: the kw' = -1 slot of an odd-width image's last pair reads one pixel past the tile
-    if (a16) cm_stage_dz<COUT, true>(cm_lds, dp + img * (Ho / 2) * (Wo / 2) * COUT, (const uint16_t *)a + img * Ho * Wo * COUT, Ho, Wo, 4, Ht * Wt + 8, activation, tid);
-    else cm_stage_dz<COUT>(cm_lds, dp + img * (Ho / 2) * (Wo / 2) * COUT, a + img * Ho * Wo * COUT, Ho, Wo, 4, Ht * Wt + 8, activation, tid);
+    for (int im = 0; im < nimg; ++im) {
+      const size_t img = (size_t)e * R + b + im;
+      // + 8 pixels of zero slack: the kw' = -1 slot of an odd-width image's last pair reads one pixel past the tile
+      if (a16) cm_stage_dz<COUT, true>(cm_lds + im * tile_bytes, dp + img * (Ho / 2) * (Wo / 2) * COUT, (const uint16_t *)a + img * Ho * Wo * COUT, Ho, Wo, 4, Ht * Wt + 8, activation, tid);
+      else cm_stage_dz<COUT>(cm_lds + im * tile_bytes, dp + img * (Ho / 2) * (Wo / 2) * COUT, a + img * Ho * Wo * COUT, Ho, Wo, 4, Ht * Wt + 8, activation, tid);
+    }
     __syncthreads();
-    float *dst = din + img * npix * CIN;
-    cm_image_f<NMF>(cm_lds, (npairs + 15) / 16, wave, so, ka,
-      [&](const int t) {
+    float *dst0 = din + ((size_t)e * R + b) * npix * CIN;
+    cm_image_f<NMF>(cm_lds, nimg * ntiles, wave, so, ka,
+      [&](const int tt) {
+        const int im = cm_div(tt, inv_nt), t = tt - im * ntiles;
         const int pc = min(t * 16 + n16, npairs - 1);
         const int yi = cm_div(pc, inv_w2), xi = 2 * (pc - yi * W2);
-        return ((yi + 4) * Wt + xi + 4) * 32;
+        return im * tile_bytes + ((yi + 4) * Wt + xi + 4) * 32;
       },
-      [&](const int t, const cm_f32x4 acc) {
+      [&](const int tt, const cm_f32x4 acc) {
+        const int im = cm_div(tt, inv_nt), t = tt - im * ntiles;
         const int p = t * 16 + n16;
         const int yi = cm_div(p, inv_w2), xi = 2 * (p - yi * W2);
+        float *dst = dst0 + (size_t)im * npix * CIN;
         if (p < npairs && 2 * g < CIN) {           // registers: 0 = (channel 2g, xi), 1 = (2g, xi + 1), 2 = (2g + 1, xi), 3 = (2g + 1, xi + 1)
           float *o = dst + (size_t)(yi * W + xi) * CIN + 2 * g;
           *reinterpret_cast<cm_f32x2 *>(o) = cm_f32x2{acc[0], acc[2]};
@@ -891,8 +906,8 @@ static inline size_t cm_lds_fwd(int mode, int H, int W, int pad, int CIN, int CO
   return std::max((size_t)ni * ((H + 2 * pad) * (W + 2 * pad) + 8) * pb, (size_t)25 * CIN * COUT * 4);
 }
 static inline size_t cm_lds_dx(int Ho, int Wo, int CIN, int COUT) { return std::max((size_t)(Ho + 8) * (Wo + 8) * 32, (size_t)25 * CIN * COUT * 4); }
-static inline size_t cm_lds_dx2x(int Ho, int Wo, int CIN, int COUT) {
-  return std::max((size_t)((Ho + 8) * (Wo + 8) + 8) * 32, (size_t)25 * CIN * COUT * 4);
+static inline size_t cm_lds_dx2x(int Ho, int Wo, int CIN, int COUT, int ni = 1) {
+  return std::max((size_t)ni * ((Ho + 8) * (Wo + 8) + 8) * 32, (size_t)25 * CIN * COUT * 4);
 }
 static inline size_t cm_lds_dw2x(int H, int W, int pad) {
   const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4, npairs = Ho * ((Wo + 1) / 2);
