@@ -38,6 +38,7 @@ CASES = [
     # B3- and B4-shaped, and shapes that leave ragged 128 x 128 x 64 tiles in every dimension
     (9, (128, 128, 128, 2), 'relu', 'regr', 'Normal', 700, 6, ('gemm_f32', 'auto')),
     (54, (256, 256, 256, 256, 7), 'relu', 'classification', 'Normal', 300, 3, ('gemm_f32', 'generic', 'auto')),
+    (54, (256, 256, 256, 7), 'relu', 'classification', 'Normal', 384, 2, ('mfma_wide_bf16x3',)),   # whole 128-tiles: k_mm3's predicate-free form
     (13, (200, 136, 3), 'tanh', 'classification', 'Normal', 1000, 2, ('generic', 'mfma_wide_bf16x3')),
     (5, (96, 2), 'sigmoid', 'regr', 'Laplace', 129, 1, ('generic', 'mfma_wide_bf16x3')),
     # edge cases: one particle, fewer rows than one MFMA block, ragged last block, one hidden layer,
