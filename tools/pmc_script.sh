@@ -18,10 +18,10 @@ out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + '/p*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'].split('(')[0][:40]
+        k = r["Kernel_Name"].split("(")[0][:64]
         agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, cs in agg.items():
-    if not any(t in k for t in ("k_grad", "k_conv5")): continue
+    if not any(t in k for t in ("k_grad", "k_conv5", "k_mm3", "k_wide")): continue
     print(k)
     for c, v in sorted(cs.items()):
         print(f'   {c:32s} n={len(v):4d} mean={sum(v)/len(v):16.1f}')
