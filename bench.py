@@ -341,6 +341,20 @@ class Leg:
         return self.wl['dtype'] if self.eng.grad_kernel in ('mfma_w128_bf16', 'lenet_bf16') or self.name in ('B2', 'B4') else 'f32'
 
 
+def secondary_leg(name, k2, w2, args, dev, torch):
+    """One bounded secondary leg of the default run: the same measurement protocol, a few steps per repetition."""
+    leg2 = Leg(name, args, None, 0, 1, dev, gather_cpu=False)
+    tm2 = leg2.measure(k2, w2, budget_s=0.5, min_reps=3, max_reps=5)
+    return {
+        'metric': 'MCLMC integrator particle-steps/s', 'value': round(leg2.E * k2 / tm2['median'], 1),
+        'unit': 'particle-steps/s', 'ms_per_step': round(tm2['median'] / k2 * 1e3, 4), 'steps': k2, 'reps': tm2['reps'],
+        'dtype': leg2.dtype(), 'config': {'workload': leg2.wl['text'], 'ensemble_per_gpu': leg2.E,
+                                          'grad_kernel': leg2.eng.grad_kernel,
+                                          'finite': bool(torch.isfinite(leg2.state.position).all().item())},
+        'roofline': None if args.no_kernel_timing else leg2.roofline(k2, args),
+        'cpu_baseline': None if args.no_cpu_baseline else leg2.cpu()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -421,17 +435,10 @@ def main():
         # BASELINE configs[2..4] (B3, B4 per GPU, B5 per GPU), bounded: a few steps per repetition, 1-16 particles on the CPU side
         secondary = {}
         for name, k2, w2 in SECONDARY:
-            leg2 = Leg(name, args, None, 0, 1, dev, gather_cpu=False)
-            tm2 = leg2.measure(k2, w2, budget_s=0.5, min_reps=3, max_reps=5)
-            secondary[name] = {
-                'metric': 'MCLMC integrator particle-steps/s', 'value': round(leg2.E * k2 / tm2['median'], 1),
-                'unit': 'particle-steps/s', 'ms_per_step': round(tm2['median'] / k2 * 1e3, 4), 'steps': k2, 'reps': tm2['reps'],
-                'dtype': leg2.dtype(), 'config': {'workload': leg2.wl['text'], 'ensemble_per_gpu': leg2.E,
-                                                  'grad_kernel': leg2.eng.grad_kernel,
-                                                  'finite': bool(torch.isfinite(leg2.state.position).all().item())},
-                'roofline': None if args.no_kernel_timing else leg2.roofline(k2, args),
-                'cpu_baseline': None if args.no_cpu_baseline else leg2.cpu()}
-            del leg2
+            try:
+                secondary[name] = secondary_leg(name, k2, w2, args, dev, torch)
+            except Exception as exc:                                # noqa: BLE001 -- a secondary leg must never cost the headline line
+                secondary[name] = {'error': f'{type(exc).__name__}: {exc}'[:300]}
             torch.cuda.empty_cache()
 
     if rank == 0:
