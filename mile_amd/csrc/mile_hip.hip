@@ -48,6 +48,7 @@ struct mile_sampler {
   // workspace
   int E_cap = 0, S_cap = 0;
   float *slabs = nullptr, *llpart = nullptr, *dK = nullptr, *lold = nullptr;
+  float *upart = nullptr;               // segmented update (d beyond the one-workgroup forms): partial sums per segment
   int32_t *arrive = nullptr;            // [E_cap] arrival tickets of the fused integrator epilogue (k_grad_w64 SPLIT)
   float *ev_X = nullptr, *ev_Xp = nullptr; void *ev_y = nullptr; int ev_cap = 0;   // evaluation (test) set staging
   float *alt_x = nullptr, *alt_u = nullptr, *alt_g = nullptr, *alt_logp = nullptr;   // ping-pong state of mile_tune
@@ -292,6 +293,8 @@ static void free_ws(mile_sampler *s) {
   if (s->slabs) (void)hipFree(s->slabs);
   if (s->llpart) (void)hipFree(s->llpart);
   if (s->dK) (void)hipFree(s->dK);
+  if (s->upart) (void)hipFree(s->upart);
+  s->upart = nullptr;
   if (s->lold) (void)hipFree(s->lold);
   if (s->alt_x) (void)hipFree(s->alt_x);
   if (s->alt_u) (void)hipFree(s->alt_u);
@@ -415,6 +418,7 @@ int32_t mile_reserve(mile_sampler *s, int32_t E) {
   HIP_TRY(hipMalloc(&s->llpart, (size_t)E * S * 4));
   HIP_TRY(hipMalloc(&s->dK, (size_t)E * 4));
   HIP_TRY(hipMalloc(&s->lold, (size_t)E * 4));
+  HIP_TRY(hipMalloc(&s->upart, ((size_t)E * ((s->ds.d + UPD_SEG - 1) / UPD_SEG) * UPD_NSUM + (size_t)E * 8) * 4));
   HIP_TRY(hipMalloc(&s->alt_x, (size_t)E * s->ds.d * 4));
   HIP_TRY(hipMalloc(&s->alt_u, (size_t)E * s->ds.d * 4));
   HIP_TRY(hipMalloc(&s->alt_g, (size_t)E * s->ds.d * 4));
@@ -528,8 +532,15 @@ static void launch_update(const UpdParams &u, int E, hipStream_t st) {
   const int nqf = u.d >> 2;
   if (nqf < 1 || nqf > UPD_NT * UPD_QMAX) {
     if (nqf >= 1 && launch_update_big(u, E, st)) return;
-    if ((u.d + 3) / 4 <= UPD_NT * UPD_QMAX) k_update<true><<<E, UPD_NT, 0, st>>>(u);
-    else k_update<false><<<E, UPD_NT, 0, st>>>(u);
+    if ((u.d + 3) / 4 <= UPD_NT * UPD_QMAX) { k_update<true><<<E, UPD_NT, 0, st>>>(u); return; }
+    if (u.upart && getenv("MILE_NO_UPD_SEG") == nullptr) {   // any d, all CUs: segments of UPD_SEG elements, sums -> chain + apply -> scalars
+      const int nseg = (u.d + UPD_SEG - 1) / UPD_SEG;
+      k_update_seg<1><<<dim3(nseg, E), UPD_NT, 0, st>>>(u, u.upart, nseg);
+      k_update_seg<2><<<dim3(nseg, E), UPD_NT, 0, st>>>(u, u.upart, nseg);
+      k_update_seg_scalars<<<(E + 255) / 256, 256, 0, st>>>(u, u.upart, nseg, E);
+      return;
+    }
+    k_update<false><<<E, UPD_NT, 0, st>>>(u);
     return;
   }
   // every row base is (pointer + e*d): vector width allowed by d and by the pointers
@@ -1672,7 +1683,7 @@ int32_t mile_step(mile_sampler *s, mile_state *state, const mile_step_args *a, v
   up.slabs = s->slabs; up.llpart = s->llpart;
   up.eps = a->step_size; up.L = a->L; up.sdc = a->sqrt_diag_cov;
   up.seed = a->seed; up.pids = a->particle_ids;
-  up.dK = s->dK; up.lold = s->lold;
+  up.dK = s->dK; up.lold = s->lold; up.upart = s->upart;
   const float b1 = (float)MCLACHLAN_B1, b2 = (float)(1.0 - 2.0 * MCLACHLAN_B1);
   const bool oso = a->refresh == MILE_REFRESH_O_STEP_O;
   const size_t Ed = (size_t)E * d;
@@ -1753,7 +1764,7 @@ int32_t mile_tune(mile_sampler *s, mile_state *state, const mile_tune_args *a, v
   up.slabs = s->slabs; up.llpart = s->llpart;
   up.eps = a->step_size; up.L = a->L; up.sdc = a->sqrt_diag_cov;
   up.seed = a->seed; up.pids = a->particle_ids;
-  up.dK = s->dK; up.lold = s->lold;
+  up.dK = s->dK; up.lold = s->lold; up.upart = s->upart;
   const float b1 = (float)MCLACHLAN_B1, b2 = (float)(1.0 - 2.0 * MCLACHLAN_B1);
   const bool oso = a->refresh == MILE_REFRESH_O_STEP_O;
   const size_t Ed = (size_t)E * d;

@@ -58,6 +58,7 @@ struct UpdParams {
   float t_mask;                  // 1 during tune1 (no averaging), 0 during tune2
   float t_var;                   // desired energy variance at this step
   float t_trust, t_decay;
+  float *upart;                  // k_update_seg: [E][segments][UPD_NSUM] partial sums + [E][8] staged scalars, or NULL
 };
 
 // B / O chain on the coefficients of {u, e, zA, zB}; norms and projections come from the
@@ -291,6 +292,173 @@ static __global__ __launch_bounds__(UPD_NT) void k_update(const UpdParams p) {
       }
       pass2(q, X, U, G, A, B);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_update for any d on all CUs: a particle's vector is cut into segments of UPD_SEG elements, one workgroup each.
+//   PHASE 1 (k_update_seg<1>): pass 1 of k_update on the segment (sums, g from the slabs), the segment's 11 partial sums to upart;
+//   PHASE 2 (k_update_seg<2>): every workgroup adds the particle's partials in segment order (deterministic), runs the scalar
+//   chain (segment 0 writes the per-particle scalars) and applies pass 2 to its segment, state re-read and noise regenerated as
+//   in the uncached k_update.  Same arithmetic per element as k_update<false>; only the order of the 11 sums differs.
+// d > 4 * UPD_NT * UPD_QMAX_BIG (B4: 213 255, LeNet: 83 126); with E = 32 particles per GPU (B5) the one-workgroup-per-particle
+// form left 7/8 of the chip idle through its serial 4-byte loops.
+#define UPD_SEG 8192
+template <int PHASE>
+static __global__ __launch_bounds__(UPD_NT) void k_update_seg(const UpdParams p, float *upart, int nseg) {
+  __shared__ float red[UPD_NW][UPD_NSUM + 1];
+  __shared__ float tot[UPD_NSUM + 1];
+  const int tid = threadIdx.x, seg = blockIdx.x, e = blockIdx.y, d = p.d;
+  const size_t base = (size_t)e * d;
+  const int q0 = seg * (UPD_SEG / 4), q1 = min((d + 3) >> 2, q0 + UPD_SEG / 4);
+  const bool from_slabs = p.flags & UPD_FROM_SLABS;
+  const bool useA = p.flags & UPD_OA, useB = p.flags & UPD_OB;
+  const uint32_t pid = p.pids ? (uint32_t)p.pids[e] : (uint32_t)e;
+  const float *sl = p.slabs + (size_t)e * p.S * p.dp;
+  float *mine = upart + ((size_t)e * nseg + seg) * UPD_NSUM;
+  if constexpr (PHASE == 1) {
+    float sm[UPD_NSUM];
+#pragma unroll
+    for (int k = 0; k < UPD_NSUM; ++k) sm[k] = 0.0f;
+    for (int q = q0 + tid; q < q1; q += UPD_NT) {
+      f32x4 A = {0, 0, 0, 0}, B = {0, 0, 0, 0};
+      if (useA && !p.zA) A = philox_normal4(q, pid, p.stepA, p.stageA, p.seed);
+      if (useB && !p.zB) B = philox_normal4(q, pid, p.stepB, p.stageB, p.seed);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int i = 4 * q + m;
+        if (i < d) {
+          float gi;
+          const float xi = p.x[base + i];
+          if (from_slabs) {
+            gi = 0.0f;
+            for (int s = 0; s < p.S; ++s) gi += sl[(size_t)s * p.dp + i];
+            const float t = (xi - p.prior_loc) / p.prior_scale;
+            if (p.prior == MILE_PRIOR_NORMAL) {
+              gi -= t / p.prior_scale;
+              sm[10] = fmaf(-0.5f * t, t, sm[10]);
+            } else {
+              gi -= (t > 0.0f ? 1.0f : (t < 0.0f ? -1.0f : 0.0f)) / p.prior_scale;
+              sm[10] -= fabsf(t);
+            }
+            p.g[base + i] = gi;
+          } else {
+            gi = p.g[base + i];
+          }
+          const float gs = p.sdc ? gi * p.sdc[base + i] : gi;
+          const float ui = p.u[base + i];
+          const float a = (useA && p.zA) ? p.zA[base + i] : A[m], b = (useB && p.zB) ? p.zB[base + i] : B[m];
+          sm[0] = fmaf(ui, ui, sm[0]); sm[1] = fmaf(ui, gs, sm[1]); sm[2] = fmaf(gs, gs, sm[2]);
+          sm[3] = fmaf(ui, a, sm[3]); sm[4] = fmaf(gs, a, sm[4]); sm[5] = fmaf(a, a, sm[5]);
+          sm[6] = fmaf(ui, b, sm[6]); sm[7] = fmaf(gs, b, sm[7]); sm[8] = fmaf(b, b, sm[8]);
+          sm[9] = fmaf(a, b, sm[9]);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < UPD_NSUM; ++k) sm[k] = wave_sum(sm[k]);
+    if ((tid & 63) == 0)
+#pragma unroll
+      for (int k = 0; k < UPD_NSUM; ++k) red[tid >> 6][k] = sm[k];
+    __syncthreads();
+    if (tid < UPD_NSUM) {
+      float t = 0.0f;
+#pragma unroll
+      for (int w = 0; w < UPD_NW; ++w) t += red[w][tid];
+      mine[tid] = t;
+    }
+    return;
+  } else {
+    if (tid < UPD_NSUM) {
+      float t = 0.0f;
+      for (int sg = 0; sg < nseg; ++sg) t += upart[((size_t)e * nseg + sg) * UPD_NSUM + tid];
+      tot[tid] = t;
+    }
+    __syncthreads();
+    float S[UPD_NSUM];
+#pragma unroll
+    for (int k = 0; k < UPD_NSUM; ++k) S[k] = tot[k];
+    const float eps = p.eps[e], L = p.L[e];
+    float logp_now;
+    if (from_slabs) {
+      float ll = 0.0f;
+      for (int s = 0; s < p.S; ++s) ll += p.llpart[(size_t)e * p.S + s];
+      const float cst = p.prior == MILE_PRIOR_NORMAL ? -(float)d * (logf(p.prior_scale) + 0.91893853320467274f)
+                                                     : -(float)d * logf(2.0f * p.prior_scale);
+      logp_now = ll + (S[10] + cst);
+    } else {
+      logp_now = p.logp[e];
+    }
+    const float gn = S[2] > 0.0f ? sqrtf(S[2]) : 1.0f;
+    const float ign = 1.0f / gn;
+    Chain ch;
+    ch.M[0][0] = S[0]; ch.M[0][1] = S[1] * ign; ch.M[0][2] = S[3]; ch.M[0][3] = S[6];
+    ch.M[1][1] = 1.0f; ch.M[1][2] = S[4] * ign; ch.M[1][3] = S[7] * ign;
+    ch.M[2][2] = S[5]; ch.M[2][3] = S[9];
+    ch.M[3][3] = S[8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if (b < a) ch.M[a][b] = ch.M[b][a];
+    ch.c[0] = 1.0f; ch.c[1] = ch.c[2] = ch.c[3] = 0.0f;
+    float dk = (p.flags & UPD_START) ? 0.0f : p.dK[e];
+    float lold = (p.flags & UPD_START) ? logp_now : p.lold[e];
+    if (p.flags & UPD_B1) dk += ch.B(eps, p.coef_b1, gn, d);
+    if (p.flags & UPD_OA) ch.O(2, p.hA * eps, L, d);
+    float info_dk = 0.0f, info_de = 0.0f;
+    if (p.flags & UPD_RECORD) {
+      info_dk = dk;
+      info_de = dk - (logp_now - lold);
+      dk = 0.0f;
+      lold = logp_now;
+    }
+    if (p.flags & UPD_OB) ch.O(3, p.hB * eps, L, d);
+    if (p.flags & UPD_B2) dk += ch.B(eps, p.coef_b2, gn, d);
+    // the per-particle scalars are rewritten by k_update_seg_scalars after every segment has read them
+    const bool any_op = p.flags & (UPD_B1 | UPD_OA | UPD_OB | UPD_B2);
+    if (seg == 0 && tid == 0) {   // staged: dK / lold / logp must stay readable for the other segments of this launch
+      float *st = upart + ((size_t)gridDim.y * nseg) * UPD_NSUM + (size_t)e * 8;
+      st[0] = dk; st[1] = lold; st[2] = logp_now; st[3] = info_dk; st[4] = info_de;
+    }
+    if (!any_op && !(p.flags & UPD_A) && !p.out_sample) return;
+    const float c0 = ch.c[0], c1 = ch.c[1] * ign, c2 = ch.c[2], c3 = ch.c[3];
+    const float ea = eps * p.coef_a;
+    for (int q = q0 + tid; q < q1; q += UPD_NT) {
+      f32x4 A = {0, 0, 0, 0}, B = {0, 0, 0, 0};
+      if (useA && !p.zA) A = philox_normal4(q, pid, p.stepA, p.stageA, p.seed);
+      if (useB && !p.zB) B = philox_normal4(q, pid, p.stepB, p.stageB, p.seed);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int i = 4 * q + m;
+        if (i < d) {
+          const float sd = p.sdc ? p.sdc[base + i] : 1.0f;
+          const float X = p.x[base + i], G = p.g[base + i] * sd;
+          const float a = (useA && p.zA) ? p.zA[base + i] : A[m], b = (useB && p.zB) ? p.zB[base + i] : B[m];
+          float v = p.u[base + i];
+          if (any_op) {
+            v = fmaf(c0, v, fmaf(c1, G, fmaf(c2, a, c3 * b)));
+            p.u[base + i] = v;
+          }
+          if (p.out_sample) p.out_sample[base + i] = X;
+          if (p.flags & UPD_A) p.x[base + i] = fmaf(ea * sd, v, X);
+        }
+      }
+    }
+  }
+}
+// the per-particle scalars of a segmented update, from the values segment 0 staged (after every segment has used the old ones)
+static __global__ __launch_bounds__(256) void k_update_seg_scalars(const UpdParams p, const float *upart, int nseg, int E) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  const float *st = upart + ((size_t)E * nseg) * UPD_NSUM + (size_t)e * 8;
+  p.dK[e] = st[0];
+  p.lold[e] = st[1];
+  if (p.flags & UPD_FROM_SLABS) p.logp[e] = st[2];
+  if ((p.flags & UPD_RECORD) && p.out_info) {
+    p.out_info[3 * e + 0] = st[2];
+    p.out_info[3 * e + 1] = st[3];
+    p.out_info[3 * e + 2] = st[4];
   }
 }
 

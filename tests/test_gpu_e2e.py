@@ -114,14 +114,15 @@ def test_preconditioned_steps_and_alignment_paths(oracle, F, hs):
     assert np.abs(s.momentum.cpu().numpy() - st.momentum).max() < 1e-4
 
 
-@pytest.mark.parametrize('F,hs,sdc', [(9, (128, 128, 2), False), (7, (129, 127, 2), True), (16, (128, 128, 128, 2), False)])
+@pytest.mark.parametrize('F,hs,sdc', [(9, (128, 128, 2), False), (7, (129, 127, 2), True), (16, (128, 128, 128, 2), False),
+                                      (9, (192, 192, 2), False), (11, (190, 203, 2), True)])
 def test_update_kernel_beyond_the_register_cache_matches_the_two_pass_form(oracle, monkeypatch, F, hs, sdc):
-    """16384 < d <= 36864 (B3: 34562): `k_update_big` -- u in registers, g parked in LDS, noise generated twice -- against
-    the two-pass `k_update` (MILE_NO_UPD_BIG) on the same Philox streams: same trajectory up to fp32 summation order, same
+    """16384 < d <= 36864 (B3: 34562): `k_update_big` -- u in registers, g parked in LDS, noise generated twice -- and beyond
+    that `k_update_seg` (segments of 8192 elements on all CUs), against the two-pass `k_update` on the same Philox streams: same trajectory up to fp32 summation order, same
     kept samples, unit momentum.  Cases: NK = 5 (16-byte rows), d % 4 == 2 with a preconditioner, NK = 9 (B3's d)."""
     ospec = oracle.ModelSpec(F, hs)
     d = ospec.n_params
-    assert 16384 < d <= 36864
+    assert d > 16384              # <= 36864: k_update_big; beyond: the segmented k_update_seg (all CUs), d = 39362 and 41461 (odd)
     E, T = 5, 6
     prob = oracle.synthetic_problem(ospec, 96, E, seed=21)
     rng = np.random.default_rng(2)
@@ -133,6 +134,7 @@ def test_update_kernel_beyond_the_register_cache_matches_the_two_pass_form(oracl
     for two_pass in (False, True):
         if two_pass:
             monkeypatch.setenv('MILE_NO_UPD_BIG', '1')
+            monkeypatch.setenv('MILE_NO_UPD_SEG', '1')
         eng = _engine(ospec, prob['X'], prob['y'], 'generic')
         s0 = eng.init(torch.from_numpy(prob['theta0']), seed=11, particle_ids=kw['particle_ids'])
         out[two_pass] = eng.step(s0, eps, L, **kw)
