@@ -94,6 +94,21 @@ def test_lenet_mfma_convolutions_match_the_bf16_recipe(LN, C, H, W, K, act, task
     assert np.abs(pw.cpu().numpy() - ll_rows).max() < 2e-3 * max(1.0, np.abs(ll_rows).max())
 
 
+@pytest.mark.parametrize('C,H,W', [(1, 12, 13), (2, 15, 12), (3, 21, 19), (4, 14, 30), (1, 33, 12), (3, 12, 37), (2, 26, 26)])
+def test_lenet_mfma_geometry_sweep(LN, C, H, W):
+    """Image sizes around the tile / pair / chunk boundaries of the MFMA convolution kernels (odd and even widths of both
+    convolutions, one and several tiles per row, pooling that crops a row or a column), small N and E: against the bf16 recipe."""
+    ospec = LN.LeNetSpec(C, H, W, 3)
+    prob = LN.synthetic_problem(ospec, 5, 2, seed=11)
+    lp_ref, g_ref = LN.logpost_and_grad_bf16(ospec, prob['theta0'].astype(np.float64), prob['X'], prob['y'])
+    lp, g = _engine(ospec, prob, 'lenet_bf16').logpost_grad(torch.from_numpy(prob['theta0']))
+    g = g.cpu().numpy()
+    assert _relerr(lp.cpu().numpy(), lp_ref) < 1e-4
+    for name, off, shape in ospec.leaves():
+        n = int(np.prod(shape))
+        assert _relerr(g[:, off:off + n], g_ref[:, off:off + n]) < 3e-3, (name, C, H, W)
+
+
 def M_pointwise(LN, ospec, th64, prob):
     out = LN.forward(ospec, th64, prob['X'], q=LN.M.bf16_round)
     return LN.M.pointwise_loglik(ospec, out, prob['y'])[0]
