@@ -54,6 +54,7 @@ WORKLOADS = {
                text='B3: protein-shaped N=36000 F=9, FCN hidden_structure [128,128,128,2] relu, Gaussian head, '
                     'StandardNormal prior, d=34562; bf16 matrix operands, fp32 accumulation/parameters/integrator'),
     'B4': dict(ensemble=128, kernel='auto', dtype='f32', peak=PEAK_FP32_MFMA_TFLOPS, steps=3, warmup=1, cpu_particles=2, cpu_seconds=5.0,
+               cpu_steps_per_call=1, cpu_warmup_call=False,   # one MCLMC step of two particles is 1.2 TFLOP on the host
                text='B4: covertype-shaped N=232404 F=54, FCN hidden_structure [256,256,256,256,7] relu, softmax head, '
                     'StandardNormal prior, d=213255, 128 particles per GPU (of 1024 over 8); layer-wise MFMA GEMMs (k_mm3), '
                     'fp32-faithful three-term bf16 products'),
@@ -88,11 +89,14 @@ def lenet_grad_flops_per_particle(C, H, W, K, N):
     return (6 * m - 2 * m1) * N
 
 
-def cpu_baseline(spec_o, prob, oracle, seconds_target=15.0, logpost_and_grad=None):
-    """The oracle's C/OpenMP restatement (oracle/cpu_mclmc.c: fp32, one particle per core, the shape
-    of the reference's own CPU run) on the host cores, on a bounded sample of the same workload: all E
-    particles, a few steps.  Falls back to the NumPy oracle if the C library cannot be built."""
+def cpu_baseline(spec_o, prob, oracle, seconds_target=15.0, logpost_and_grad=None, steps_per_call=2, warmup_call=True):
+    """The oracle's C/OpenMP restatement (oracle/cpu_mclmc.c: fp32; one particle per core -- the shape of the reference's
+    own CPU run -- or, with fewer particles than cores, a particle's rows over the cores) on the host cores, on a bounded
+    sample of the same workload: E particles, a few steps.  Any FCN (ReLU / tanh / sigmoid, Gaussian or softmax head);
+    LeNet, which the C port does not restate, takes the NumPy oracle.  `cores` is what this process may really use
+    (affinity mask and cgroup quota), in both forms."""
     import numpy as np
+    from oracle.cpu_c import effective_cpus
     dt = np.float32
     E, d = prob['theta0'].shape
     rng = np.random.default_rng(0)
@@ -104,9 +108,10 @@ def cpu_baseline(spec_o, prob, oracle, seconds_target=15.0, logpost_and_grad=Non
         x = prob['theta0'].astype(dt).copy()
         u = (prob['u0'] / np.linalg.norm(prob['u0'], axis=1, keepdims=True)).astype(dt)
         logp, g = port.logpost_grad(x)
-        T = 2
+        T = steps_per_call
         noise = rng.standard_normal((T, 2, E, d), dtype=dt)
-        port.steps(x, u, logp, g, prob['eps'], prob['L'], noise)          # warm-up (threads, caches)
+        if warmup_call:
+            port.steps(x, u, logp, g, prob['eps'], prob['L'], noise)      # warm-up (threads, caches)
         n, t0 = 0, time.perf_counter()
         while True:
             port.steps(x, u, logp, g, prob['eps'], prob['L'], noise)
@@ -114,16 +119,18 @@ def cpu_baseline(spec_o, prob, oracle, seconds_target=15.0, logpost_and_grad=Non
             el = time.perf_counter() - t0
             if el > seconds_target or n >= 400:
                 break
+        how = 'one particle per thread' if E >= port.threads else "each particle's rows split over the threads"
         return {'value': E * n / el, 'unit': 'particle-steps/s', 'cores': int(port.threads), 'kind': 'port',
                 'sample': f'{n} MCLMC steps of {E} particles of the workload (oracle/cpu_mclmc.c, fp32, OpenMP threads='
-                          f'{port.threads}, one particle per thread), {el:.1f} s'}
+                          f'{port.threads}, {how}), {el:.1f} s'}
     except Exception as exc:                                                # noqa: BLE001
-        note = f' [C port unavailable: {type(exc).__name__}]'
+        note = f' [C port not used: {type(exc).__name__}]'
+    cores = effective_cpus()                                                # affinity mask / cgroup quota, not the machine's CPU count
     try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=cores)                                     # OpenBLAS would otherwise start one thread per visible CPU
+    except Exception:                                                       # noqa: BLE001
+        pass
     lg = logpost_and_grad or oracle.logpost_and_grad
     f = lambda th: lg(spec_o, th, prob['X'], prob['y'])
     st = oracle.mclmc_init(f, prob['theta0'].astype(dt), prob['u0'].astype(dt))
@@ -297,7 +304,7 @@ class Leg:
         achieved = flops / avg_s / 1e12
         info = eng.grad_launch_info(E)
         traffic = None   # PMC counters cannot be read from inside the run: last committed measurement of this kernel
-        for rdir in ('r02', 'r01'):
+        for rdir in ('r03', 'r02', 'r01'):
             tj = ROOT / 'profiles' / rdir / 'traffic.json'
             if tj.exists() and self.name == 'B2' and E == WORKLOADS['B2']['ensemble'] and info['kernel'] == 'k_grad_w64':
                 traffic = json.loads(tj.read_text())['hbm_bytes_per_launch']
@@ -309,25 +316,33 @@ class Leg:
                 'avg_launch_us': round(avg_s * 1e6, 2), 'launches_timed': n_launch,
                 'flop_per_launch': flops}
         if self.lenet:
-            roof['kernel_note'] = ('avg_launch_us is one whole gradient: five convolution launches (the MFMA share), pooling fused, three Dense '
-                                   'layers as rocBLAS SGEMMs, head; priced against the bf16 dense peak although only the convolution products '
-                                   'run on it')
+            roof['kernel_note'] = ('avg_launch_us is one whole gradient: five convolution launches (implicit GEMMs on bf16 MFMA, pooling '
+                                   'fused), the three Dense layers as hand-written k_mm3 GEMMs with fp32-faithful three-term bf16 products '
+                                   '(lenet_bf16 uses no library kernel), head; priced whole against the bf16 dense peak although the Dense '
+                                   'share runs six products per fp32 product')
+        # The *_bf16x3 kernels do fp32 ARITHMETIC (exact products of three-term bf16 splits, fp32 accumulation) on the bf16
+        # matrix pipe: six bf16 MFMA products of 32 clk per 16-deep chunk instead of eight fp32 MFMAs of 64 clk.  The roof that
+        # bounds them is therefore their own instruction mix, not the fp32-MFMA peak -- pricing six-product GEMMs against the
+        # fp32 peak flatters them.  `peak` / `frac` are the mix bound; the fp32-peak figures stay alongside.
+        mix_scale = None
         if eng.grad_kernel == 'mfma_wide_bf16x3':
-            # every product is six bf16 MFMA products (32 clk per 16-deep chunk) instead of eight fp32 MFMAs of 64 clk
             roof['mix'] = 'all Dense products as 6 bf16 MFMA products of exact 3-term bf16 splits (fp32-faithful), layer-wise GEMMs'
-            roof['peak_mix_bound'] = round(peak * 8 * 64 / (6 * 32), 1)
-            roof['frac_of_mix_bound'] = round(achieved / (peak * 8 * 64 / (6 * 32)), 4)
+            mix_scale = 8 * 64 / (6 * 32)
         if eng.grad_kernel == 'mfma_w64_bf16x3':
-            # `peak` stays the fp32 MFMA peak (the arithmetic is fp32: exact products of 3-term bf16 splits, fp32
-            # accumulation).  The kernel's own MFMA-pipe floor is lower than an all-fp32 kernel's: hidden forward /
-            # dH / dW tiles cost 6 bf16 MFMAs x 32 clk per 16-deep chunk instead of 8 fp32 MFMAs x 64 clk (only
-            # the first layer stays on the fp32 MFMA).  `frac_of_mix_bound` prices `achieved` against that mix.
+            # only the first layer (F <= 16 inputs) stays on the fp32 MFMA: per 32-row block 8 fq fp32 MFMAs of 64 clk and
+            # 144 (nh - 1) bf16 MFMAs of 32 clk against 8 fq + 192 (nh - 1) fp32 MFMAs for the all-fp32 kernel
             nh, fq = len(spec.hidden_structure) - 1, (spec.in_features + 7) // 8
             clk_fp32 = (8 * fq + 192 * (nh - 1)) * 64
             clk_mix = 8 * fq * 64 + (nh - 1) * 144 * 32
             roof['mix'] = 'hidden-layer products as 6 bf16 MFMA products of exact 3-term bf16 splits (fp32-faithful)'
-            roof['peak_mix_bound'] = round(peak * clk_fp32 / clk_mix, 1)
-            roof['frac_of_mix_bound'] = round(achieved / (peak * clk_fp32 / clk_mix), 4)
+            mix_scale = clk_fp32 / clk_mix
+        if mix_scale is not None:
+            roof['peak_fp32_mfma'] = peak
+            roof['frac_of_fp32_peak'] = round(achieved / peak, 4)
+            roof['peak'] = round(peak * mix_scale, 1)
+            roof['frac'] = round(achieved / (peak * mix_scale), 4)
+            roof['peak_note'] = ('peak = the MFMA-pipe bound of this kernel\'s own instruction mix (fp32-exact three-term bf16 products); '
+                                 'frac_of_fp32_peak prices the same algorithmic fp32 FLOPs against the 157.3 TFLOP/s fp32-MFMA peak')
         return roof
 
     def cpu(self):
@@ -335,7 +350,8 @@ class Leg:
         prob1 = {k: (v[:Ec] if k in ('theta0', 'u0', 'eps', 'L') else v) for k, v in self.prob.items()}
         if self.lenet:      # NumPy oracle of the same recipe (no C port for the convolutions)
             return cpu_baseline(self.spec_o, prob1, self.oracle, self.wl['cpu_seconds'], logpost_and_grad=self.lenet_oracle.logpost_and_grad_bf16)
-        return cpu_baseline(self.spec_o, prob1, self.oracle, self.wl['cpu_seconds'])
+        return cpu_baseline(self.spec_o, prob1, self.oracle, self.wl['cpu_seconds'], steps_per_call=self.wl.get('cpu_steps_per_call', 2),
+                            warmup_call=self.wl.get('cpu_warmup_call', True))
 
     def dtype(self):
         return self.wl['dtype'] if self.eng.grad_kernel in ('mfma_w128_bf16', 'lenet_bf16') or self.name in ('B2', 'B4') else 'f32'
@@ -462,8 +478,13 @@ def main():
                        'ensemble_per_gpu': E, 'ensemble_total': E * world, 'n_thinning': N_THINNING,
                        'integrator': 'isokinetic McLachlan, O-step-O refresh, 2 full-batch gradients/step',
                        'noise': 'Philox4x32-10 counter RNG', 'grad_kernel': leg.eng.grad_kernel,
-                       'parallelism': f'particles sharded {E}/GPU x {world}, RCCL all-gather of kept samples per {CHUNK}-step chunk '
-                                      + ('(async, overlapping the next chunk)' if args.async_gather else '(ordered on the compute stream)'),
+                       'parallelism': f'particles sharded {E}/GPU x {world}, '
+                                      + ('no collective (one rank, no process group)' if dist is None else
+                                         (f'{dist.get_backend()} all-gather of kept samples per {CHUNK}-step chunk '
+                                          + ('-- a ONE-GPU REHEARSAL of the N-rank control flow over gloo through host memory, not RCCL '
+                                             if args.rehearse_one_gpu else '(RCCL over xGMI) ')
+                                          + ('(async, overlapping the next chunk)' if args.async_gather else '(ordered on the compute stream)'))),
+                       'collective_backend': None if dist is None else dist.get_backend(),
                        'finite': finite},
             'timing': {'repetitions': tm['reps'], 'reported': 'median repetition of the K-step timed region',
                        'ms_per_step_min': round(tm['min'] / args.steps * 1e3, 5),

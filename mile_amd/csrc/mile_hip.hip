@@ -46,7 +46,8 @@ struct mile_sampler {
   int N = 0, Npad = 0, Fp = 0, Npb = 0;
   int win_begin = 0, win_count = 0;     // mile_set_row_window: rows [begin, begin + count) only (count 0 = all)
   // workspace
-  int E_cap = 0, S_cap = 0;
+  int E_cap = 0;
+  size_t ES_cap = 0;   // slab rows (particles x row splits) the workspace holds: fewer particles may split the rows further
   float *slabs = nullptr, *llpart = nullptr, *dK = nullptr, *lold = nullptr;
   float *upart = nullptr;               // segmented update (d beyond the one-workgroup forms): partial sums per segment
   int32_t *arrive = nullptr;            // [E_cap] arrival tickets of the fused integrator epilogue (k_grad_w64 SPLIT)
@@ -305,8 +306,10 @@ static void free_ws(mile_sampler *s) {
   s->tune_info = nullptr;
   if (s->arrive) (void)hipFree(s->arrive);
   s->arrive = nullptr;
+  if (s->dbg_buf) (void)hipFree(s->dbg_buf);   // sized from the slab-row capacity
+  s->dbg_buf = nullptr;
   s->slabs = s->llpart = s->dK = s->lold = nullptr;
-  s->E_cap = s->S_cap = 0;
+  s->E_cap = 0; s->ES_cap = 0;
 }
 
 int32_t mile_destroy(mile_sampler *s) {
@@ -412,21 +415,25 @@ int32_t mile_reserve(mile_sampler *s, int32_t E) {
   // capacity must cover whichever grad kernel is selected later
   int S = std::max(choose_S(s, E, MILE_GRAD_GENERIC), w64_supported(s->spec) ? choose_S(s, E, MILE_GRAD_MFMA_W64) : 1);
   if (w128b_supported(s->spec)) S = std::max(S, choose_S(s, E, MILE_GRAD_MFMA_W128_BF16));
-  if (E <= s->E_cap && S <= s->S_cap) return MILE_OK;
+  // A smaller ensemble splits the rows of a particle over MORE workgroups (S grows as E shrinks): capacity is counted in
+  // slab rows E * S, and a later call with fewer particles must neither fail nor shrink what a larger one reserved.
+  if (E <= s->E_cap && (size_t)E * S <= s->ES_cap) return MILE_OK;
+  const int En = std::max(E, s->E_cap);
+  const size_t ESn = std::max((size_t)E * S, s->ES_cap);
   free_ws(s);
-  HIP_TRY(hipMalloc(&s->slabs, (size_t)E * S * ((s->ds.d + 3) / 4 * 4) * 4));
-  HIP_TRY(hipMalloc(&s->llpart, (size_t)E * S * 4));
-  HIP_TRY(hipMalloc(&s->dK, (size_t)E * 4));
-  HIP_TRY(hipMalloc(&s->lold, (size_t)E * 4));
-  HIP_TRY(hipMalloc(&s->upart, ((size_t)E * ((s->ds.d + UPD_SEG - 1) / UPD_SEG) * UPD_NSUM + (size_t)E * 8) * 4));
-  HIP_TRY(hipMalloc(&s->alt_x, (size_t)E * s->ds.d * 4));
-  HIP_TRY(hipMalloc(&s->alt_u, (size_t)E * s->ds.d * 4));
-  HIP_TRY(hipMalloc(&s->alt_g, (size_t)E * s->ds.d * 4));
-  HIP_TRY(hipMalloc(&s->alt_logp, (size_t)E * 4));
-  HIP_TRY(hipMalloc(&s->arrive, ((size_t)E * 4 + 15) / 16 * 16));
-  HIP_TRY(hipMemset(s->arrive, 0, ((size_t)E * 4 + 15) / 16 * 16));
-  s->E_cap = E;
-  s->S_cap = S;
+  HIP_TRY(hipMalloc(&s->slabs, ESn * ((s->ds.d + 3) / 4 * 4) * 4));
+  HIP_TRY(hipMalloc(&s->llpart, ESn * 4));
+  HIP_TRY(hipMalloc(&s->dK, (size_t)En * 4));
+  HIP_TRY(hipMalloc(&s->lold, (size_t)En * 4));
+  HIP_TRY(hipMalloc(&s->upart, ((size_t)En * ((s->ds.d + UPD_SEG - 1) / UPD_SEG) * UPD_NSUM + (size_t)En * 8) * 4));
+  HIP_TRY(hipMalloc(&s->alt_x, (size_t)En * s->ds.d * 4));
+  HIP_TRY(hipMalloc(&s->alt_u, (size_t)En * s->ds.d * 4));
+  HIP_TRY(hipMalloc(&s->alt_g, (size_t)En * s->ds.d * 4));
+  HIP_TRY(hipMalloc(&s->alt_logp, (size_t)En * 4));
+  HIP_TRY(hipMalloc(&s->arrive, ((size_t)En * 4 + 15) / 16 * 16));
+  HIP_TRY(hipMemset(s->arrive, 0, ((size_t)En * 4 + 15) / 16 * 16));
+  s->E_cap = En;
+  s->ES_cap = ESn;
   return MILE_OK;
 }
 
@@ -471,6 +478,7 @@ static void launch_update_al(const UpdParams &u, int E, int nk, hipStream_t st) 
   if constexpr (!SDC) {                                                                          \
     if (kind == UPD_KIND_MID) { k_update_fast<NK_, AL, SDC, UPD_KIND_MID><<<E, nt, 0, st>>>(u); break; } \
     if (kind == UPD_KIND_REC) { k_update_fast<NK_, AL, SDC, UPD_KIND_REC><<<E, nt, 0, st>>>(u); break; } \
+    if (kind == UPD_KIND_TUNE) { k_update_fast<NK_, AL, SDC, UPD_KIND_TUNE><<<E, nt, 0, st>>>(u); break; } \
   }                                                                                              \
   k_update_fast<NK_, AL, SDC><<<E, nt, 0, st>>>(u); break;
   switch (nk) {
@@ -545,7 +553,7 @@ static void launch_update(const UpdParams &u, int E, hipStream_t st) {
   }
   // every row base is (pointer + e*d): vector width allowed by d and by the pointers
   int al = (u.d % 4 == 0) ? 4 : ((u.d % 2 == 0) ? 2 : 1);
-  const void *ptrs[] = {u.x, u.u, u.g, u.slabs, u.sdc, u.zA, u.zB, u.out_sample, u.x_in, u.u_in, u.g_in, u.t_avg};
+  const void *ptrs[] = {u.x, u.u, u.g, u.slabs, u.sdc, u.zA, u.zB, u.out_sample, u.x_in, u.u_in, u.g_in, u.t_avg, u.u_rec};
   for (const void *q : ptrs)
     if (q) al = std::min(al, ptr_align(q));
   const int nk = (nqf + UPD_NT - 1) / UPD_NT;
@@ -586,7 +594,7 @@ static hipError_t launch_w64(const GradParams &gp, const W64Fuse &fz, int E, hip
 // 8-byte aligned rows everywhere (the epilogue is the AL = 2 form), no preconditioner, d within its register cache.
 static bool fuse_ok(const mile_sampler *s, int kernel, const UpdParams &u) {
   if (!MILE_W64_EPILOGUE_ON || kernel != MILE_GRAD_MFMA_W64_BF16X3 || getenv("MILE_NO_FUSE")) return false;
-  if (u.sdc || (u.d & 1)) return false;
+  if (u.sdc || (u.d & 1) || u.u_rec) return false;   // (the merged warm-up launch exists as a stand-alone kernel only)
   const int nh = s->spec.n_layers - 1, fq = s->Fp / 8;
   if (fq != 1) return false;                       // the F > 8 kernels are built without the epilogue (mile_grad_w64.h)
   const int nk = nh == 2 ? w64_fuse_nk<2, 1>() : w64_fuse_nk<3, 1>();
@@ -1253,7 +1261,7 @@ static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t s
   if (!s->X) return fail(MILE_ERR_STATE, "no data: call mile_set_data first");
   const int kernel = resolved_kernel(s);
   const int S = choose_S(s, E, kernel);
-  if (E > s->E_cap || S > s->S_cap) return fail(MILE_ERR_STATE, "workspace too small: call mile_reserve(E) first");
+  if (E > s->E_cap || (size_t)E * S > s->ES_cap) return fail(MILE_ERR_STATE, "workspace too small: call mile_reserve(E) first");
   GradParams gp;
   gp.spec = s->ds;
   gp.theta = theta;
@@ -1276,7 +1284,7 @@ static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t s
   { const char *dv = getenv("MILE_DEBUG"); gp.dbg = dv ? atoi(dv) : 0; }
   gp.dbg_buf = nullptr;
   if ((gp.dbg & 16) && !s->dbg_buf) HIP_TRY(hipMalloc(&s->dbg_buf, 64));
-  if ((gp.dbg & 32) && !s->dbg_buf) HIP_TRY(hipMalloc(&s->dbg_buf, (size_t)s->E_cap * s->S_cap * 128));
+  if ((gp.dbg & 32) && !s->dbg_buf) HIP_TRY(hipMalloc(&s->dbg_buf, s->ES_cap * 128));
   gp.dbg_buf = s->dbg_buf;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (s->timing) {
@@ -1674,7 +1682,7 @@ int32_t mile_step(mile_sampler *s, mile_state *state, const mile_step_args *a, v
   const int kernel = resolved_kernel(s);
   const int S = choose_S(s, E, kernel);
   if (!s->X) return fail(MILE_ERR_STATE, "no data: call mile_set_data first");
-  if (E > s->E_cap || S > s->S_cap) return fail(MILE_ERR_STATE, "workspace too small: call mile_reserve(E) first");
+  if (E > s->E_cap || (size_t)E * S > s->ES_cap) return fail(MILE_ERR_STATE, "workspace too small: call mile_reserve(E) first");
 
   UpdParams up{};
   up.d = d; up.E = E; up.S = S; up.dp = (d + 3) / 4 * 4;
@@ -1753,7 +1761,7 @@ int32_t mile_tune(mile_sampler *s, mile_state *state, const mile_tune_args *a, v
   HIP_TRY(hipSetDevice(s->device));
   if (!s->X) return fail(MILE_ERR_STATE, "no data: call mile_set_data first");
   const int S = choose_S(s, E, resolved_kernel(s));
-  if (E > s->E_cap || S > s->S_cap) return fail(MILE_ERR_STATE, "workspace too small: call mile_reserve(E) first");
+  if (E > s->E_cap || (size_t)E * S > s->ES_cap) return fail(MILE_ERR_STATE, "workspace too small: call mile_reserve(E) first");
 
   struct Buf { float *x, *u, *g, *logp; };
   const Buf A{state->position, state->momentum, state->logdensity_grad, state->logdensity};
@@ -1837,12 +1845,18 @@ int32_t mile_tune(mile_sampler *s, mile_state *state, const mile_tune_args *a, v
   UpdParams probe = up;
   probe.x = A.x; probe.u = A.u; probe.g = A.g; probe.x_in = B.x; probe.u_in = B.u; probe.g_in = B.g;
   probe.zA = a->noise; probe.t_avg = a->stream_average;
+  if (a->n_steps > 1) probe.u_rec = A.u;
   const bool fused = fuse_ok(s, resolved_kernel(s), probe);
   if (fused) HIP_TRY(hipMemsetAsync(s->arrive, 0, ((size_t)E * 4 + 15) / 16 * 16, st));
+  // Per step: grad . update(B, A) . grad . update(B, O, record + TUNE [. O, B, A of the next step with the NEW step size]) --
+  // four launches, as a sampling step (mile_step).  Step i works in buffer W_i and leaves the accepted state there; its last
+  // launch writes the next step's working position / momentum into the other buffer, which until then held the state before
+  // step i (what handle_nans reverts to): W_{i+1} = K_i, K_{i+1} = W_i, no copies.
+  const bool no_merge = getenv("MILE_TUNE_NO_MERGE") != nullptr;      // dev / test: the five-launch form of rounds 1-2
   for (int i = 0; i < a->n_steps; ++i) {
     const Buf &cur = (i & 1) ? B : A, &nxt = (i & 1) ? A : B;
     const int64_t gstep = a->step_offset + i;
-    {  // O(z1) . B(b1) . A(1/2): reads the current state, writes the other buffer (free backup)
+    if (i == 0 || no_merge) {  // O(z1) . B(b1) . A(1/2): reads the current state, writes the other buffer (free backup)
       UpdParams u = up;
       set_state(u, nxt);
       u.x_in = cur.x; u.u_in = cur.u; u.g_in = cur.g; u.logp_in = cur.logp;
@@ -1859,7 +1873,7 @@ int32_t mile_tune(mile_sampler *s, mile_state *state, const mile_tune_args *a, v
       const int rc = grad_then_update(s, nxt.x, E, u, fused, st);
       if (rc) return rc;
     }
-    {  // B(b1) . O(z2) . record + tuner (step-size predictor, handle_nans, streaming averages)
+    {  // B(b1) . O(z2) . record + tuner (step-size predictor, handle_nans, streaming averages) [+ the next step's O, B, A]
       UpdParams u = up;
       set_state(u, nxt);
       u.flags = UPD_FROM_SLABS | UPD_B1 | UPD_OA | UPD_RECORD | UPD_TUNE;
@@ -1873,6 +1887,14 @@ int32_t mile_tune(mile_sampler *s, mile_state *state, const mile_tune_args *a, v
       u.t_var = target_var(sp);
       u.t_trust = a->trust_in_estimate; u.t_decay = a->decay_rate;
       if (a->out_info) u.out_info = a->out_info + (size_t)i * E * 3;
+      if (i + 1 < a->n_steps && !no_merge) {
+        u.flags |= UPD_B2 | UPD_A | (oso ? UPD_OB : 0);
+        u.zB = noise_at(i + 1, 0); u.stepB = (uint32_t)(gstep + 1); u.stageB = 0; u.hB = 0.5f;
+        u.coef_b2 = b1; u.coef_a = 0.5f;
+        u.x_in = nxt.x; u.u_in = nxt.u;          // the step ran in nxt; its accepted state stays there ...
+        u.x_acc = nxt.x; u.u_rec = nxt.u;
+        u.x = cur.x; u.u = cur.u;                // ... and the next step's working state goes to the other buffer
+      }
       const int rc = grad_then_update(s, nxt.x, E, u, fused, st);
       if (rc) return rc;
     }

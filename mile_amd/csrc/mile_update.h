@@ -59,6 +59,11 @@ struct UpdParams {
   float t_var;                   // desired energy variance at this step
   float t_trust, t_decay;
   float *upart;                  // k_update_seg: [E][segments][UPD_NSUM] partial sums + [E][8] staged scalars, or NULL
+  // ---- merged warm-up launch (UPD_TUNE together with the NEXT step's O, B, A; k_update_fast only) ----
+  // x_in / u_in name the buffer W the step ran in; the ACCEPTED state stays there (x_acc = W.x, u_rec = W.u, g, logp), and the
+  // next step's working position / momentum go to x / u (the other buffer, which bk_* names: the state before this step).
+  float *u_rec;                  // [E, d] momentum at the record point (nan_to_num'd), or NULL: plain record launch
+  float *x_acc;                  // [E, d] == x_in, writable: a rejected chain gets bk_x back here
 };
 
 // B / O chain on the coefficients of {u, e, zA, zB}; norms and projections come from the
@@ -541,11 +546,14 @@ __device__ __forceinline__ float ld1_shared(const float *q) {
 // prior, step-O refresh).
 #define UPD_KIND_MID (UPD_FROM_SLABS | UPD_B1 | UPD_A | UPD_NO_G)
 #define UPD_KIND_REC (UPD_FROM_SLABS | UPD_B1 | UPD_OA | UPD_RECORD | UPD_OB | UPD_B2 | UPD_A | UPD_NO_G)
+#define UPD_KIND_TUNE (UPD_FROM_SLABS | UPD_B1 | UPD_OA | UPD_RECORD | UPD_TUNE | UPD_OB | UPD_B2 | UPD_A)   // warm-up steady state
 // BIG (d beyond UPD_QMAX quads per thread, up to UPD_QMAX_BIG): only u stays in registers, x is read twice, the gradient waits in the
 // workgroup's LDS array `gl` ([NK][nt] quads, <= 147 KB) and the O-step noise is generated twice (pass 1 for the sums, pass 2
 // for the update) -- five register-resident arrays of 9 quads do not fit the 128 registers a 1024-thread workgroup has.
+// Returns true (workgroup-uniform) when a merged warm-up launch could not take the next step's O, B, A along -- the step was
+// rejected, or the accepted state needed nan_to_num -- and the caller has to run them from the stored state (upd_tune_restart).
 template <int NK, int AL, bool SDC, bool COH, int CF = -1, bool BIG = false>
-__device__ __forceinline__ void upd_fast_body(const UpdParams &p, const int e, const int tid, const int nt,
+__device__ __forceinline__ bool upd_fast_body(const UpdParams &p, const int e, const int tid, const int nt,
                                               float (*red)[UPD_NSUM + 1], float *bc, long long *stamps = nullptr,
                                               f32x4 *gl = nullptr) {
   const int d = p.d;
@@ -561,6 +569,7 @@ __device__ __forceinline__ void upd_fast_body(const UpdParams &p, const int e, c
   const __amdgpu_buffer_rsrc_t sl_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sl), 0, p.S * p.dp * 4, 0x00020000);
   const float *xin = p.x_in ? p.x_in : p.x, *uin = p.u_in ? p.u_in : p.u, *gin = p.g_in ? p.g_in : p.g;
   const bool tune = flags & UPD_TUNE;
+  const bool merged = tune && p.u_rec != nullptr;      // record point + tuner + the next step's O, B, A in one launch
   const bool store_g = from_slabs && !(flags & UPD_NO_G);
   const float ips = 1.0f / p.prior_scale;
   const bool normal = CF >= 0 ? true : p.prior == MILE_PRIOR_NORMAL;
@@ -741,6 +750,9 @@ __device__ __forceinline__ void upd_fast_body(const UpdParams &p, const int e, c
   // ---- warm-up tuner at the record point (predictor + handle_nans, warmup.py:271-326,468-483) ----
   bool t_ok = true;
   float t_wgt = 0.0f, t_Wold = 0.0f;
+  float eps_next = eps;                                     // the step size the ops after the record point run with
+  const float r0 = ch.c[0], r1 = ch.c[1] * ign, r2 = ch.c[2], r3 = ch.c[3];   // momentum at the record point
+  bool t_simple = true;
   if (tune) {
     constexpr float FMAX = 3.4028234663852886e38f;
     t_ok = S[11] == 0.0f;                                   // jnp.all(jnp.isfinite(position))
@@ -759,6 +771,11 @@ __device__ __forceinline__ void upd_fast_body(const UpdParams &p, const int e, c
     t_Wold = p.t_W[e];
     t_wgt = (1.0f - p.t_mask) * (t_ok ? 1.0f : 0.0f) * en;
     logp_now = t_ok ? nan_to_num(logp_now) : p.bk_logp[e];    // the logdensity leaf of the state the chain continues from
+    eps_next = en;                                            // params_new.step_size: what the next kernel step uses
+    // the next step's ops can be formed from THIS launch's Gram matrix only if the accepted momentum / gradient are the
+    // vectors it was built from, i.e. nan_to_num changed nothing: all finite
+    t_simple = t_ok && isfinite(S[2]) && isfinite(S[0]) && isfinite(r0) && isfinite(r1) && isfinite(r2) && isfinite(r3);
+    if (merged) lold = logp_now;
     if (tid == 0) {
       p.t_eps[e] = en;
       p.t_eps_max[e] = emax;
@@ -767,8 +784,8 @@ __device__ __forceinline__ void upd_fast_body(const UpdParams &p, const int e, c
       p.t_W[e] = t_Wold + t_wgt;
     }
   }
-  if (flags & UPD_OB) ch.O(3, p.hB * eps, L, d);
-  if (flags & UPD_B2) dk += ch.B(eps, p.coef_b2, gn, d);
+  if (flags & UPD_OB) ch.O(3, p.hB * eps_next, L, d);
+  if (flags & UPD_B2) dk += ch.B(eps_next, p.coef_b2, gn, d);
   if (tid == 0) {
     p.dK[e] = dk;
     p.lold[e] = lold;
@@ -779,7 +796,8 @@ __device__ __forceinline__ void upd_fast_body(const UpdParams &p, const int e, c
       p.out_info[3 * e + 2] = info_de;
     }
     bc[0] = ch.c[0]; bc[1] = ch.c[1] * ign; bc[2] = ch.c[2]; bc[3] = ch.c[3];
-    bc[4] = eps * p.coef_a; bc[5] = t_ok ? 1.0f : 0.0f; bc[6] = t_Wold; bc[7] = t_wgt;
+    bc[4] = eps_next * p.coef_a; bc[5] = t_ok ? 1.0f : 0.0f; bc[6] = t_Wold; bc[7] = t_wgt;
+    if (merged) { bc[8] = r0; bc[9] = r1; bc[10] = r2; bc[11] = r3; bc[12] = t_simple ? 1.0f : 0.0f; }
   }
   }
   __syncthreads();
@@ -791,13 +809,17 @@ __device__ __forceinline__ void upd_fast_body(const UpdParams &p, const int e, c
   const bool t_ok = bc[5] != 0.0f;
   const float t_Wold = bc[6], t_wgt = bc[7];
   if (tune && !t_ok) {   // handle_nans: this chain keeps its previous state (rare, workgroup-uniform)
+    float *xo = merged ? p.x_acc : p.x, *uo = merged ? p.u_rec : p.u;
     for (int i = tid; i < d; i += nt) {
-      p.x[base + i] = p.bk_x[base + i];
-      p.u[base + i] = p.bk_u[base + i];
+      xo[base + i] = p.bk_x[base + i];
+      uo[base + i] = p.bk_u[base + i];
       p.g[base + i] = p.bk_g[base + i];
     }
-    return;
+    return merged;       // merged: the next step's O, B, A still have to run, from the restored state
   }
+  float rc0 = 0.0f, rc1 = 0.0f, rc2 = 0.0f;
+  bool simple = true;
+  if (merged) { rc0 = bc[8]; rc1 = bc[9]; rc2 = bc[10]; simple = bc[12] != 0.0f; }
   const bool t_acc = tune && p.t_mask == 0.0f;              // streaming_average_update of [x, x^2]
   const float t_den = 1.0f / (t_Wold + t_wgt);              // zero_prevention = mask = 0 here
 #pragma unroll
@@ -832,10 +854,17 @@ __device__ __forceinline__ void upd_fast_body(const UpdParams &p, const int e, c
         st4<AL>(a1, m1);
       }
       f32x4 v = cu[kq];
+      if (merged) {   // the accepted state's momentum (record point; zB is not part of it) stays in the step's own buffer
+        f32x4 ur;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) ur[m] = nan_to_num(fmaf(rc0, cu[kq][m], fmaf(rc1, cg[k][m], rc2 * ca[k][m])));
+        st4<AL>(p.u_rec + o, ur);
+        if (!simple) continue;   // O, B, A of the next step run from the stored (nan_to_num'd) state instead
+      }
       if (any_op) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) v[m] = fmaf(c0, cu[kq][m], fmaf(c1, cg[k][m], fmaf(c2, ca[k][m], c3 * cb[k][m])));
-        if (tune) {   // nan_to_num(next_state.momentum), warmup.py:478-482
+        if (tune && !merged) {   // nan_to_num(next_state.momentum), warmup.py:478-482
 #pragma unroll
           for (int m = 0; m < 4; ++m) v[m] = nan_to_num(v[m]);
         }
@@ -858,19 +887,41 @@ __device__ __forceinline__ void upd_fast_body(const UpdParams &p, const int e, c
       *a1 = (t_Wold * *a1 + t_wgt * tx * tx) * t_den;
     }
     float v = tu;
-    if (any_op) { v = fmaf(c0, tu, fmaf(c1, tg, fmaf(c2, ta, c3 * tb))); if (tune) v = nan_to_num(v); p.u[to] = v; }
-    if (p.out_sample) p.out_sample[to] = tx;
-    if (doA) p.x[to] = fmaf(ea * tsd, v, tx);
+    if (merged) p.u_rec[to] = nan_to_num(fmaf(rc0, tu, fmaf(rc1, tg, rc2 * ta)));
+    if (!merged || simple) {
+      if (any_op) { v = fmaf(c0, tu, fmaf(c1, tg, fmaf(c2, ta, c3 * tb))); if (tune && !merged) v = nan_to_num(v); p.u[to] = v; }
+      if (p.out_sample) p.out_sample[to] = tx;
+      if (doA) p.x[to] = fmaf(ea * tsd, v, tx);
+    }
   }
+  return merged && !simple;
+}
+
+// The next step's O(z1) . B(b1) . A(1/2) for a chain whose merged warm-up launch could not form them (rejected step, or an
+// accepted state that nan_to_num changed): the ordinary first launch of a step, from the state the record launch left in the
+// step's own buffer, with the step size the tuner has just written.
+template <int NK, int AL, bool SDC>
+__device__ __forceinline__ void upd_tune_restart(const UpdParams &p, const int e, const int tid, const int nt,
+                                                 float (*red)[UPD_NSUM + 1], float *bc) {
+  __syncthreads();                                   // the record pass's global stores / LDS reads are done
+  UpdParams q = p;
+  q.flags = UPD_START | UPD_B2 | UPD_A | (p.flags & UPD_OB);
+  q.x_in = p.x_acc; q.u_in = p.u_rec; q.g_in = p.g; q.logp_in = p.logp;
+  q.eps = p.t_eps;
+  q.u_rec = nullptr; q.x_acc = nullptr; q.out_info = nullptr; q.out_sample = nullptr; q.zA = nullptr;
+  upd_fast_body<NK, AL, SDC, false, -1>(q, e, tid, nt, red, bc);
 }
 
 template <int NK, int AL, bool SDC, int CF = -1>
 static __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
   __shared__ float red[UPD_NW][UPD_NSUM + 1];
-  __shared__ float bc[8];
+  __shared__ float bc[16];
   // launched with the fewest waves that still give NK quads per thread (nt = blockDim.x <= UPD_NT, a multiple of 64): the
   // kernel is VALU-bound on half the chip (E workgroups), so idle padded lanes cost real time (d = 8834: 768 threads, not 1024)
-  upd_fast_body<NK, AL, SDC, false, CF>(p, blockIdx.x, threadIdx.x, blockDim.x, red, bc);
+  const bool again = upd_fast_body<NK, AL, SDC, false, CF>(p, blockIdx.x, threadIdx.x, blockDim.x, red, bc);
+  if constexpr (CF < 0 || (CF & UPD_TUNE) != 0) {
+    if (again) upd_tune_restart<NK, AL, SDC>(p, blockIdx.x, threadIdx.x, blockDim.x, red, bc);
+  }
 }
 
 // d beyond the register cache (B3: d = 34 562): NK = 5 .. UPD_QMAX_BIG quads per thread, g parked in dynamic LDS
@@ -879,7 +930,7 @@ static __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p
 template <int NK, int AL, bool SDC, int CF = -1>
 static __global__ __launch_bounds__(UPD_NT) void k_update_big(const UpdParams p) {
   __shared__ float red[UPD_NW][UPD_NSUM + 1];
-  __shared__ float bc[8];
+  __shared__ float bc[16];
   extern __shared__ __attribute__((aligned(16))) char upd_gl[];
   upd_fast_body<NK, AL, SDC, false, CF, true>(p, blockIdx.x, threadIdx.x, blockDim.x, red, bc, nullptr, reinterpret_cast<f32x4 *>(upd_gl));
 }
@@ -889,6 +940,7 @@ static inline int upd_kind(const UpdParams &u) {
   if (u.prior != MILE_PRIOR_NORMAL || u.sdc || getenv("MILE_NO_UPD_KIND")) return -1;
   if (u.flags == UPD_KIND_MID) return UPD_KIND_MID;
   if (u.flags == UPD_KIND_REC) return UPD_KIND_REC;
+  if (u.flags == UPD_KIND_TUNE && u.u_rec) return UPD_KIND_TUNE;
   return -1;
 }
 

@@ -122,9 +122,10 @@ class Engine:
         _lib.check(self.lib.mile_set_row_window(self._h, int(begin), int(count)), self.lib)
 
     def reserve(self, E: int):
-        if E > self._E_reserved:
-            _lib.check(self.lib.mile_reserve(self._h, int(E)), self.lib)
-            self._E_reserved = int(E)
+        # always asked: a SMALLER ensemble splits each particle's rows over more workgroups and may need more slab rows than
+        # the larger one reserved (mile_reserve returns at once when the workspace already fits, and never shrinks it)
+        _lib.check(self.lib.mile_reserve(self._h, int(E)), self.lib)
+        self._E_reserved = max(self._E_reserved, int(E))
 
     def set_grad_kernel(self, name: str):
         _lib.check(self.lib.mile_set_grad_kernel(self._h, _lib.GRAD_KERNEL_IDS[name]), self.lib)

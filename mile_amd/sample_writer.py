@@ -14,17 +14,75 @@ import struct
 import subprocess
 import sys
 import threading
+import zlib
 from pathlib import Path
 
 import numpy as np
 
 
+# ---- the .npz container, written directly --------------------------------------------------------------------------
+# np.savez_compressed (what the reference calls, callbacks.py:42) = a zip archive with one deflated `<key>.npy` member per
+# array.  fp32 posterior samples do not compress (measured on a B2 sample: 35 336 -> 34 637 bytes, 2 %) while zlib spends
+# 0.85 ms per 35 KB file on them at ANY level >= 1 -- 128 000 files of the stock schedule = 109 core-seconds, 3-4x the
+# stepping time of the whole sampling phase on the 16 host cores of a GPU.  The files here are the same archives -- same
+# member names, same .npy headers, method 8 (deflate), readable by np.load / zipfile exactly like numpy's own -- whose
+# deflate streams are written at MILE_NPZ_DEFLATE_LEVEL (default 0: stored blocks, 2 % larger files, 0.05 ms instead of
+# 0.85 ms of zlib per file; 6 = numpy's level).
+_NPY_HEADERS: dict = {}
+
+
+def _npy_header(dtype: np.dtype, shape: tuple) -> bytes:
+    key = (dtype.str, tuple(shape))
+    h = _NPY_HEADERS.get(key)
+    if h is None:
+        import io
+        from numpy.lib import format as fmt
+        bio = io.BytesIO()
+        fmt.write_array_header_1_0(bio, {'descr': fmt.dtype_to_descr(dtype), 'fortran_order': False, 'shape': tuple(shape)})
+        h = _NPY_HEADERS[key] = bio.getvalue()
+    return h
+
+
+def deflate_level() -> int:
+    try:
+        return min(9, max(0, int(os.environ.get('MILE_NPZ_DEFLATE_LEVEL', '0'))))
+    except ValueError:
+        return 0
+
+
+def write_npz(path, members, level: int | None = None):
+    """members: [(key, C-contiguous ndarray)] -> a zip archive np.load reads as np.savez_compressed's."""
+    level = deflate_level() if level is None else level
+    parts, central, offset = [], [], 0
+    for key, a in members:
+        a = np.asarray(a)
+        if not a.flags.c_contiguous:              # (np.ascontiguousarray would turn a 0-d array into shape (1,))
+            a = np.array(a, order='C')
+        data = _npy_header(a.dtype, a.shape) + a.tobytes()
+        crc = zlib.crc32(data)
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = co.compress(data) + co.flush()
+        name = (key + '.npy').encode()
+        # local file header / central directory entry (PKZIP appnote 4.3.7, 4.3.12): version 2.0, no flags, method 8
+        # (deflate), DOS time 00:00 / date 1980-01-01, sizes < 4 GiB (no zip64 extra field needed)
+        parts.append(struct.pack('<IHHHHHIIIHH', 0x04034b50, 20, 0, 8, 0, 0x21, crc, len(comp), len(data), len(name), 0) + name)
+        parts.append(comp)
+        central.append(struct.pack('<IHHHHHHIIIHHHHHII', 0x02014b50, 20, 20, 0, 8, 0, 0x21, crc, len(comp), len(data), len(name),
+                                   0, 0, 0, 0, 0o600 << 16, offset) + name)
+        offset += len(parts[-2]) + len(comp)
+    cd = b''.join(central)
+    end = struct.pack('<IHHHHIIH', 0x06054b50, 0, 0, len(central), len(central), len(cd), offset, 0)
+    with open(path, 'wb') as f:
+        f.write(b''.join(parts) + cd + end)
+
+
 def write_chain_samples(leaves, rows: np.ndarray, base: str, idx: int, ns) -> int:
     path = Path(base) / f'{int(idx)}'
     path.mkdir(parents=True, exist_ok=True)
+    level = deflate_level()
     for row, n in zip(rows, ns):
-        np.savez_compressed(path / f'sample_{int(n)}.npz',
-                            **{name: row[off:off + int(np.prod(shape))].reshape(shape) for name, off, shape in leaves})
+        write_npz(path / f'sample_{int(n)}.npz',
+                  [(name, row[off:off + int(np.prod(shape))].reshape(shape)) for name, off, shape in leaves], level)
     return len(ns)
 
 

@@ -14,7 +14,8 @@ LIB = HERE / 'libcpu_mclmc.so'
 
 class CpuSpec(C.Structure):
     _fields_ = [('n_layers', C.c_int), ('in_features', C.c_int), ('widths', C.c_int * 16), ('w_off', C.c_int * 16),
-                ('b_off', C.c_int * 16), ('d', C.c_int), ('prior_loc', C.c_float), ('prior_scale', C.c_float)]
+                ('b_off', C.c_int * 16), ('d', C.c_int), ('prior_loc', C.c_float), ('prior_scale', C.c_float),
+                ('activation', C.c_int), ('task', C.c_int), ('prior', C.c_int)]
 
 
 def effective_cpus() -> int:
@@ -52,18 +53,24 @@ def _p(a):
 
 
 class CpuPort:
-    """ReLU / regression / Normal-prior FCN only (BASELINE configs B1, B2)."""
+    """Any FCN of the oracle's ModelSpec with < 11 layers: relu / tanh / sigmoid, regression or classification head, Normal
+    or Laplace prior (BASELINE configs B1-B4)."""
+
+    ACT = {'relu': 0, 'tanh': 1, 'sigmoid': 2}
+    TASK = {'regr': 0, 'classification': 1}
+    PRIOR = {'Normal': 0, 'Laplace': 1}
 
     def __init__(self, spec, X, y):
-        assert spec.activation == 'relu' and spec.task == 'regr' and spec.prior == 'Normal'
+        assert len(spec.hidden_structure) < 11        # ravel_pytree order == layer order only below 'layer10'
         self.lib = load()
         self.cs = CpuSpec()
         w = (C.c_int * len(spec.hidden_structure))(*spec.hidden_structure)
         self.lib.cpu_spec_init(C.byref(self.cs), spec.in_features, len(spec.hidden_structure), w,
-                               C.c_float(spec.prior_loc), C.c_float(spec.prior_scale))
+                               C.c_float(spec.prior_loc), C.c_float(spec.prior_scale), self.ACT[spec.activation],
+                               self.TASK[spec.task], self.PRIOR[spec.prior])
         assert self.cs.d == spec.n_params
         self.X = np.ascontiguousarray(X, np.float32)
-        self.y = np.ascontiguousarray(y, np.float32)
+        self.y = np.ascontiguousarray(y, np.float32 if spec.task == 'regr' else np.int32)
         self.lib.cpu_set_threads(effective_cpus())
         self.threads = int(self.lib.cpu_threads())
 

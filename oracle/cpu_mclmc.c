@@ -8,7 +8,11 @@
  * Follows: Dense stack src/flax_building_blocks/basic.py:42-61; Gaussian head + nansum
  * src/training/probabilistic.py:92-100; Normal prior src/training/priors.py:101-108; blackjax 1.2.2
  * isokinetic McLachlan MCLMC step with explicit noise.
- * Supported: ReLU, regression head, Normal prior (what BASELINE configs B1/B2 use).
+ * Supported: ReLU / tanh / sigmoid (src/config/models/base.py:25-39), Gaussian regression head and softmax classification
+ * head (probabilistic.py:92-109), Normal and Laplace priors (priors.py:101-128): BASELINE configs B1-B4.
+ * Parallelism: one particle per thread when there are at least as many particles as threads (the reference's layout);
+ * with fewer particles (B4's bounded sample) the rows of a particle are split over the threads instead, each with its own
+ * gradient accumulator, summed in thread order.
  */
 #include <math.h>
 #include <stdint.h>
@@ -20,9 +24,14 @@
 
 #define MAXL 16
 
+enum { ACT_RELU = 0, ACT_TANH = 1, ACT_SIGMOID = 2 };
+enum { TASK_REGR = 0, TASK_CLASS = 1 };
+enum { PRIOR_NORMAL = 0, PRIOR_LAPLACE = 1 };
+
 typedef struct {
   int n_layers, in_features, widths[MAXL], w_off[MAXL], b_off[MAXL], d;
   float prior_loc, prior_scale;
+  int activation, task, prior;
 } cpu_spec;
 
 void cpu_set_threads(int n) {
@@ -42,8 +51,10 @@ int cpu_threads(void) {
 }
 
 /* ravel_pytree order for < 11 layers: per layer bias[out], kernel[in,out] */
-void cpu_spec_init(cpu_spec *s, int in_features, int n_layers, const int *widths, float loc, float scale) {
+void cpu_spec_init(cpu_spec *s, int in_features, int n_layers, const int *widths, float loc, float scale, int activation,
+                   int task, int prior) {
   s->n_layers = n_layers; s->in_features = in_features; s->prior_loc = loc; s->prior_scale = scale;
+  s->activation = activation; s->task = task; s->prior = prior;
   int off = 0, fin = in_features;
   for (int l = 0; l < n_layers; ++l) {
     s->widths[l] = widths[l];
@@ -54,20 +65,22 @@ void cpu_spec_init(cpu_spec *s, int in_features, int n_layers, const int *widths
   s->d = off;
 }
 
-/* one particle: log posterior and gradient; scratch holds activations for RB rows at a time */
+/* log-likelihood of rows [r_begin, r_end) of one particle and its gradient ACCUMULATED into g (caller zeroes it);
+ * scratch holds activations for RB rows at a time.  y: float targets (regr) or int32 labels (classification). */
 #define RB 64
-static float logpost_grad_one(const cpu_spec *s, const float *th, const float *X, const float *y, int N, float *g,
-                              float *scratch) {
-  const int nl = s->n_layers, F = s->in_features, d = s->d;
+static double loglik_rows(const cpu_spec *s, const float *th, const float *X, const void *yv, int r_begin, int r_end, float *g,
+                          float *scratch) {
+  const int nl = s->n_layers, F = s->in_features, K = s->widths[nl - 1];
   int maxw = F, sumw = F;
   for (int l = 0; l < nl; ++l) { if (s->widths[l] > maxw) maxw = s->widths[l]; sumw += s->widths[l]; }
   float *act = scratch;                 /* [RB][sumw] */
   float *dz = act + RB * sumw;          /* [RB][maxw] */
   float *dzn = dz + RB * maxw;          /* [RB][maxw] */
-  memset(g, 0, sizeof(float) * d);
+  const float *yf = (const float *)yv;
+  const int32_t *yi = (const int32_t *)yv;
   double ll = 0.0;
-  for (int r0 = 0; r0 < N; r0 += RB) {
-    const int nr = N - r0 < RB ? N - r0 : RB;
+  for (int r0 = r_begin; r0 < r_end; r0 += RB) {
+    const int nr = r_end - r0 < RB ? r_end - r0 : RB;
     for (int r = 0; r < nr; ++r) memcpy(act + r * sumw, X + (size_t)(r0 + r) * F, sizeof(float) * F);
     int aoff = 0, fin = F;
     for (int l = 0; l < nl; ++l) {
@@ -82,24 +95,43 @@ static float logpost_grad_one(const cpu_spec *s, const float *th, const float *X
           const float *Wi = W + (size_t)i * fo;
           for (int o = 0; o < fo; ++o) z[o] += ai * Wi[o];
         }
-        if (l < nl - 1)
-          for (int o = 0; o < fo; ++o) z[o] = z[o] > 0.0f ? z[o] : 0.0f;
+        if (l < nl - 1) {
+          if (s->activation == ACT_RELU) for (int o = 0; o < fo; ++o) z[o] = z[o] > 0.0f ? z[o] : 0.0f;
+          else if (s->activation == ACT_TANH) for (int o = 0; o < fo; ++o) z[o] = tanhf(z[o]);
+          else for (int o = 0; o < fo; ++o) z[o] = 1.0f / (1.0f + expf(-z[o]));
+        }
       }
       aoff += fin; fin = fo;
     }
-    /* Gaussian head */
-    for (int r = 0; r < nr; ++r) {
-      const float *out = act + r * sumw + aoff;
-      const float mu = out[0], sr = out[1];
-      const float es = expf(sr);
-      float sig = es < 1e-6f ? 1e-6f : (es > 1e6f ? 1e6f : es);
-      const int unclipped = es > 1e-6f && es < 1e6f;
-      const float rr = (y[r0 + r] - mu) / sig;
-      float l1 = -0.5f * rr * rr - logf(sig) - 0.91893853320467274f;
-      float dmu = rr / sig, ds = unclipped ? rr * rr - 1.0f : 0.0f;
-      if (isnan(l1) || isnan(es) || isnan(mu)) { l1 = 0.0f; dmu = 0.0f; ds = 0.0f; }
-      ll += l1;
-      dz[r * maxw + 0] = dmu; dz[r * maxw + 1] = ds;
+    if (s->task == TASK_REGR) {           /* Gaussian head, probabilistic.py:92-100 */
+      for (int r = 0; r < nr; ++r) {
+        const float *out = act + r * sumw + aoff;
+        const float mu = out[0], sr = out[1];
+        const float es = expf(sr);
+        float sig = es < 1e-6f ? 1e-6f : (es > 1e6f ? 1e6f : es);
+        const int unclipped = es > 1e-6f && es < 1e6f;
+        const float rr = (yf[r0 + r] - mu) / sig;
+        float l1 = -0.5f * rr * rr - logf(sig) - 0.91893853320467274f;
+        float dmu = rr / sig, ds = unclipped ? rr * rr - 1.0f : 0.0f;
+        if (isnan(l1) || isnan(es) || isnan(mu)) { l1 = 0.0f; dmu = 0.0f; ds = 0.0f; }
+        ll += l1;
+        dz[r * maxw + 0] = dmu; dz[r * maxw + 1] = ds;
+      }
+    } else {                              /* log_softmax(out)[y], probabilistic.py:101-109 */
+      for (int r = 0; r < nr; ++r) {
+        const float *out = act + r * sumw + aoff;
+        float m = out[0];
+        for (int k = 1; k < K; ++k) m = out[k] > m ? out[k] : m;
+        float se = 0.0f;
+        for (int k = 0; k < K; ++k) se += expf(out[k] - m);
+        const float lse = m + logf(se);
+        const int lab = yi[r0 + r];
+        float l1 = out[lab] - lse;
+        const int bad = isnan(l1);
+        if (bad) l1 = 0.0f;
+        ll += l1;
+        for (int k = 0; k < K; ++k) dz[r * maxw + k] = bad ? 0.0f : (k == lab ? 1.0f : 0.0f) - expf(out[k] - lse);
+      }
     }
     /* backward */
     float *dzc = dz, *dzo = dzn;
@@ -124,23 +156,38 @@ static float logpost_grad_one(const cpu_spec *s, const float *th, const float *X
             const float *Wi = W + (size_t)i * fo;
             float acc = 0.0f;
             for (int o = 0; o < fo; ++o) acc += Wi[o] * dzr[o];
-            dn[i] = a[i] > 0.0f ? acc : 0.0f;
+            const float h = a[i];             /* the layer's activation output */
+            dn[i] = s->activation == ACT_RELU ? (h > 0.0f ? acc : 0.0f)
+                  : s->activation == ACT_TANH ? acc * (1.0f - h * h) : acc * h * (1.0f - h);
           }
         }
       }
       float *t = dzc; dzc = dzo; dzo = t;
     }
   }
-  /* prior */
+  return ll;
+}
+
+static double log_prior_add(const cpu_spec *s, const float *th, float *g) {
   double lp = 0.0;
+  const int d = s->d;
   const float sc = s->prior_scale, loc = s->prior_loc;
-  for (int i = 0; i < d; ++i) {
-    const float t = (th[i] - loc) / sc;
-    lp += -0.5 * (double)t * t;
-    g[i] -= t / sc;
+  if (s->prior == PRIOR_NORMAL) {
+    for (int i = 0; i < d; ++i) {
+      const float t = (th[i] - loc) / sc;
+      lp += -0.5 * (double)t * t;
+      g[i] -= t / sc;
+    }
+    lp += -(double)d * (log((double)sc) + 0.91893853320467274);
+  } else {
+    for (int i = 0; i < d; ++i) {
+      const float t = (th[i] - loc) / sc;
+      lp += -fabs((double)t);
+      g[i] -= (t > 0.0f ? 1.0f : (t < 0.0f ? -1.0f : 0.0f)) / sc;
+    }
+    lp += -(double)d * log(2.0 * (double)sc);
   }
-  lp += -(double)d * (log((double)sc) + 0.91893853320467274);
-  return (float)(ll + lp);
+  return lp;
 }
 
 static size_t scratch_floats(const cpu_spec *s) {
@@ -149,8 +196,60 @@ static size_t scratch_floats(const cpu_spec *s) {
   return (size_t)RB * (sumw + 2 * maxw);
 }
 
-void cpu_logpost_grad(const cpu_spec *s, const float *theta, int E, const float *X, const float *y, int N,
+/* one particle on the calling thread */
+static float logpost_grad_one(const cpu_spec *s, const float *th, const float *X, const void *y, int N, float *g, float *scratch) {
+  memset(g, 0, sizeof(float) * s->d);
+  const double ll = loglik_rows(s, th, X, y, 0, N, g, scratch);
+  return (float)(ll + log_prior_add(s, th, g));
+}
+
+/* one particle with its rows split over all threads (fewer particles than threads): per-thread gradient accumulators in
+ * `gpart` [threads][d], summed in thread order */
+static float logpost_grad_split(const cpu_spec *s, const float *th, const float *X, const void *y, int N, float *g, float *gpart,
+                                int nthreads) {
+  const int d = s->d;
+  const int nblk = (N + RB - 1) / RB;
+  double llp[256];
+  if (nthreads > 256) nthreads = 256;
+#pragma omp parallel num_threads(nthreads)
+  {
+#ifdef _OPENMP
+    const int t = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+    const int t = 0, nt = 1;
+#endif
+    float *scratch = (float *)malloc(sizeof(float) * scratch_floats(s));
+    float *gl = gpart + (size_t)t * d;
+    memset(gl, 0, sizeof(float) * d);
+    const int b0 = (int)((long long)nblk * t / nt), b1 = (int)((long long)nblk * (t + 1) / nt);
+    const int r0 = b0 * RB, r1 = b1 * RB < N ? b1 * RB : N;
+    llp[t] = r0 < r1 ? loglik_rows(s, th, X, y, r0, r1, gl, scratch) : 0.0;
+    free(scratch);
+#pragma omp barrier
+#pragma omp for schedule(static)
+    for (int i = 0; i < d; ++i) {
+      float acc = 0.0f;
+      for (int k = 0; k < nt; ++k) acc += gpart[(size_t)k * d + i];
+      g[i] = acc;
+    }
+#pragma omp single
+    { for (int k = nt; k < 256; ++k) llp[k] = 0.0; }
+  }
+  double ll = 0.0;
+  for (int k = 0; k < nthreads; ++k) ll += llp[k];
+  return (float)(ll + log_prior_add(s, th, g));
+}
+
+void cpu_logpost_grad(const cpu_spec *s, const float *theta, int E, const float *X, const void *y, int N,
                       float *logp, float *grad) {
+  const int nth = cpu_threads();
+  if (E < nth && nth > 1) {
+    float *gpart = (float *)malloc(sizeof(float) * (size_t)nth * s->d);
+    for (int e = 0; e < E; ++e)
+      logp[e] = logpost_grad_split(s, theta + (size_t)e * s->d, X, y, N, grad + (size_t)e * s->d, gpart, nth);
+    free(gpart);
+    return;
+  }
 #pragma omp parallel
   {
     float *scratch = (float *)malloc(sizeof(float) * scratch_floats(s));
@@ -188,37 +287,52 @@ static void ostep(float *u, const float *z, int d, float h, float L) {          
   for (int i = 0; i < d; ++i) u[i] *= inv;
 }
 
+static void steps_one(const cpu_spec *s, float *xe, float *ue, float *lpe, float *ge, int e, int E, float h, float Le,
+                      const float *noise, int n_steps, const float *X, const void *y, int N, float *info, float *scratch,
+                      float *gpart, int nsplit) {
+  const int d = s->d;
+  const float b1 = 0.1931833275037836f, b2 = 1.0f - 2.0f * 0.1931833275037836f;
+  for (int t = 0; t < n_steps; ++t) {
+    const float *z1 = noise + (((size_t)t * 2 + 0) * E + e) * d, *z2 = noise + (((size_t)t * 2 + 1) * E + e) * d;
+    const float l_old = *lpe;
+    ostep(ue, z1, d, 0.5f * h, Le);
+    float dK = bstep(ue, ge, d, h, b1);
+    for (int i = 0; i < d; ++i) xe[i] += h * 0.5f * ue[i];
+    *lpe = gpart ? logpost_grad_split(s, xe, X, y, N, ge, gpart, nsplit) : logpost_grad_one(s, xe, X, y, N, ge, scratch);
+    dK += bstep(ue, ge, d, h, b2);
+    for (int i = 0; i < d; ++i) xe[i] += h * 0.5f * ue[i];
+    *lpe = gpart ? logpost_grad_split(s, xe, X, y, N, ge, gpart, nsplit) : logpost_grad_one(s, xe, X, y, N, ge, scratch);
+    dK += bstep(ue, ge, d, h, b1);
+    ostep(ue, z2, d, 0.5f * h, Le);
+    if (info) {
+      float *o = info + ((size_t)t * E + e) * 3;
+      o[0] = *lpe; o[1] = dK; o[2] = dK - *lpe + l_old;
+    }
+  }
+}
+
 /* n_steps kernel steps (O . B A B A B . O) of every particle, explicit noise [n_steps, 2, E, d];
  * info [n_steps, E, 3] = (logdensity, kinetic_change, energy_change) or NULL */
 void cpu_mclmc_steps(const cpu_spec *s, float *x, float *u, float *logp, float *g, int E, const float *eps,
-                     const float *L, const float *noise, int n_steps, const float *X, const float *y, int N,
+                     const float *L, const float *noise, int n_steps, const float *X, const void *y, int N,
                      float *info) {
   const int d = s->d;
-  const float b1 = 0.1931833275037836f, b2 = 1.0f - 2.0f * 0.1931833275037836f;
+  const int nth = cpu_threads();
+  if (E < nth && nth > 1) {   /* fewer particles than threads: particles in turn, rows over the threads */
+    float *gpart = (float *)malloc(sizeof(float) * (size_t)nth * d);
+    for (int e = 0; e < E; ++e)
+      steps_one(s, x + (size_t)e * d, u + (size_t)e * d, logp + e, g + (size_t)e * d, e, E, eps[e], L[e], noise, n_steps, X, y, N,
+                info, NULL, gpart, nth);
+    free(gpart);
+    return;
+  }
 #pragma omp parallel
   {
     float *scratch = (float *)malloc(sizeof(float) * scratch_floats(s));
 #pragma omp for schedule(dynamic, 1)
-    for (int e = 0; e < E; ++e) {
-      float *xe = x + (size_t)e * d, *ue = u + (size_t)e * d, *ge = g + (size_t)e * d;
-      for (int t = 0; t < n_steps; ++t) {
-        const float *z1 = noise + (((size_t)t * 2 + 0) * E + e) * d, *z2 = noise + (((size_t)t * 2 + 1) * E + e) * d;
-        const float l_old = logp[e], h = eps[e];
-        ostep(ue, z1, d, 0.5f * h, L[e]);
-        float dK = bstep(ue, ge, d, h, b1);
-        for (int i = 0; i < d; ++i) xe[i] += h * 0.5f * ue[i];
-        logp[e] = logpost_grad_one(s, xe, X, y, N, ge, scratch);
-        dK += bstep(ue, ge, d, h, b2);
-        for (int i = 0; i < d; ++i) xe[i] += h * 0.5f * ue[i];
-        logp[e] = logpost_grad_one(s, xe, X, y, N, ge, scratch);
-        dK += bstep(ue, ge, d, h, b1);
-        ostep(ue, z2, d, 0.5f * h, L[e]);
-        if (info) {
-          float *o = info + ((size_t)t * E + e) * 3;
-          o[0] = logp[e]; o[1] = dK; o[2] = dK - logp[e] + l_old;
-        }
-      }
-    }
+    for (int e = 0; e < E; ++e)
+      steps_one(s, x + (size_t)e * d, u + (size_t)e * d, logp + e, g + (size_t)e * d, e, E, eps[e], L[e], noise, n_steps, X, y, N,
+                info, scratch, NULL, 1);
     free(scratch);
   }
 }

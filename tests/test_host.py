@@ -302,6 +302,37 @@ def test_writer_pool_subprocesses_write_the_same_files(tmp_path):
         assert a.files == b.files and all(np.array_equal(a[k], b[k]) for k in a.files)
 
 
+def test_npz_container_is_what_numpy_writes_and_reads(tmp_path):
+    """mile_amd.sample_writer.write_npz (round 3: the per-sample files without numpy's / zipfile's per-member overhead and, by
+    default, with STORED deflate blocks -- fp32 samples do not compress) against np.savez_compressed (callbacks.py:42 of the
+    reference): same member names in the same order, same .npy payloads bit for bit, deflate method, intact CRCs; np.load
+    and zipfile read both alike, at every deflate level."""
+    import zipfile
+    from mile_amd.sample_writer import write_npz
+    rng = np.random.default_rng(0)
+    mem = [('fcn.layer0.bias', rng.standard_normal(16).astype(np.float32)),
+           ('fcn.layer0.kernel', rng.standard_normal((5, 16)).astype(np.float32)),
+           ('labels', np.arange(7, dtype=np.int32)), ('scalar', np.float32(3.5).reshape(())),
+           ('empty', np.zeros((0, 3), np.float32)), ('strided', rng.standard_normal((4, 12)).astype(np.float32)[:, ::2])]      # neither C- nor F-contiguous
+    np.savez_compressed(tmp_path / 'ref.npz', **dict(mem))
+    with zipfile.ZipFile(tmp_path / 'ref.npz') as zr:
+        ref_members = {i.filename: zr.read(i.filename) for i in zr.infolist()}
+        ref_order = [i.filename for i in zr.infolist()]
+    for level in (0, 1, 6):
+        f = tmp_path / f'l{level}.npz'
+        write_npz(f, mem, level)
+        with zipfile.ZipFile(f) as zf:
+            assert zf.testzip() is None
+            assert [i.filename for i in zf.infolist()] == ref_order
+            assert all(i.compress_type == zipfile.ZIP_DEFLATED for i in zf.infolist())
+            assert all(zf.read(n) == ref_members[n] for n in ref_order)         # identical .npy bytes (header + data)
+        with np.load(f, allow_pickle=False) as z:
+            assert z.files == [k for k, _ in mem]
+            for k, a in mem:
+                assert z[k].dtype == a.dtype and z[k].shape == a.shape and np.array_equal(z[k], a)
+    assert (tmp_path / 'l0.npz').stat().st_size < 1.2 * (tmp_path / 'ref.npz').stat().st_size + 1024
+
+
 def test_tabular_loader_normalises_and_splits(tmp_path):
     from mile_amd.config import DataConfig
     from mile_amd.dataset import TabularLoader

@@ -9,10 +9,18 @@ from oracle import mclmc_oracle as O
 pytestmark = pytest.mark.skipif(shutil.which('gcc') is None, reason='needs gcc')
 
 
-@pytest.mark.parametrize('F,hs,N,E', [(5, (64, 64, 64, 2), 150, 5), (5, (16, 16, 2), 77, 3), (9, (24, 2), 64, 2)])
-def test_c_port_matches_numpy_oracle(F, hs, N, E):
+@pytest.mark.parametrize('F,hs,N,E,kw', [
+    (5, (64, 64, 64, 2), 150, 5, {}), (5, (16, 16, 2), 77, 3, {}), (9, (24, 2), 64, 2, {}),
+    # round 3: the heads / activations / priors of BASELINE config 4 and of the reference's classification YAMLs, and the
+    # rows-over-threads form a bounded B4 sample takes (fewer particles than threads: E = 1 whenever the host has > 1 CPU)
+    (54, (32, 32, 7), 300, 1, dict(task='classification')),
+    (11, (32, 7), 130, 4, dict(activation='sigmoid', task='classification')),
+    (7, (12, 9, 3), 90, 3, dict(activation='tanh', task='classification', prior='Laplace', prior_scale=0.5)),
+    (5, (20, 2), 200, 1, dict(activation='tanh')),
+])
+def test_c_port_matches_numpy_oracle(F, hs, N, E, kw):
     from oracle.cpu_c import CpuPort
-    spec = O.ModelSpec(F, hs)
+    spec = O.ModelSpec(F, hs, **kw)
     pr = O.synthetic_problem(spec, N, E, seed=2)
     port = CpuPort(spec, pr['X'], pr['y'])
     lp, g = port.logpost_grad(pr['theta0'])
