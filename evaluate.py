@@ -49,6 +49,53 @@ def main():
            'lppd': float(lppd(pw).item()), 'nll_mean': float(-pw.mean().item()),
            'running_lppd_last': float(running_lppd(pw)[-1].item()),
            'nonfinite_chains_total': int(bad_chains.sum()), 'nonfinite_samples': int((~torch.isfinite(torch.from_numpy(samples)).all(dim=-1)).sum().item())}
+    # per chain (src/inference/evaluation.py:520-529 prints the same per-chain LPPD): the ensemble figure above is a logsumexp
+    # over all chains, which a few chains thrown into a bad region (profiles/r03/01_*) barely move -- their own LPPD shows them
+    kept_ids = np.arange(len(bad_chains))[~bad_chains] if (args.drop_nonfinite and bad_chains.any() and not bad_chains.all()) \
+        else np.arange(len(bad_chains))
+    pc = [float(lppd(pw[c:c + 1]).item()) for c in range(pw.shape[0])]
+    out['chain_ids'] = [int(c) for c in kept_ids]
+    out['per_chain_lppd'] = pc
+    out['per_chain_lppd_median'] = float(np.nanmedian(pc))
+    # RMSE of the posterior-mean prediction (src/inference/evaluation.py:509-518: mean over (chain, sample) of the predicted
+    # mean, regression FCNs): a plain torch forward of the Dense stack on the device -- evaluation tooling, not the hot path
+    if cfg.data.task == 'regr' and cfg.model.model == 'FCN':
+        dev = torch.device(args.device)
+        xt = torch.from_numpy(x).to(dev)
+        flat = torch.from_numpy(samples.reshape(-1, samples.shape[-1]))
+        act = {'relu': torch.relu, 'tanh': torch.tanh, 'sigmoid': torch.sigmoid}[cfg.model.activation]
+        leaves = {n: (o, sh) for n, o, sh in spec.leaves()}
+        nl = len(spec.hidden_structure)
+        mu_sum = torch.zeros(x.shape[0], dtype=torch.float64, device=dev)
+        n_ok = 0
+        S_ = samples.shape[1]
+        mu_chain = torch.zeros((samples.shape[0], x.shape[0]), dtype=torch.float64, device=dev)     # per-chain mean prediction
+        for c0 in range(0, flat.shape[0], 512):
+            th = flat[c0:c0 + 512].to(dev)
+            h = xt[None].expand(th.shape[0], -1, -1)
+            for li in range(nl):
+                ob, shb = leaves[f'fcn.layer{li}.bias']
+                ok_, shk = leaves[f'fcn.layer{li}.kernel']
+                h = torch.baddbmm(th[:, None, ob:ob + shb[0]], h, th[:, ok_:ok_ + shk[0] * shk[1]].reshape(-1, shk[0], shk[1]))
+                if li < nl - 1:
+                    h = act(h)
+            mu = h[..., 0]
+            fin_rows = torch.isfinite(mu).all(dim=1)
+            mu_sum += mu[fin_rows].double().sum(dim=0)
+            n_ok += int(fin_rows.sum())
+            idx = torch.arange(c0, c0 + th.shape[0], device=dev) // S_
+            mu_chain.index_add_(0, idx, torch.nan_to_num(mu.double(), nan=0.0, posinf=0.0, neginf=0.0))
+        if n_ok:
+            yt = torch.from_numpy(np.ascontiguousarray(y)).to(dev).double().reshape(-1)
+            out['rmse'] = float(torch.sqrt(((yt - mu_sum / n_ok) ** 2).mean()).item())
+            rc = torch.sqrt(((yt[None] - mu_chain / S_) ** 2).mean(dim=1))
+            out['per_chain_rmse'] = [float(v) for v in rc.cpu()]
+            out['per_chain_rmse_median'] = float(rc.median().item())
+    # dead chains: a tuned step size of 0 / NaN in warmup_params.txt (profiles/r03/01_dead_chains_mechanism.md)
+    wp = exp / 'warmup_params.txt'
+    if wp.exists():
+        eps = np.array([float(v) for v in wp.read_text().split('\n')[0].split(',')])
+        out['dead_chains_step_size_zero_or_nan'] = int((~(np.isfinite(eps) & (eps > 0))).sum())
     # ESS and ESS/s (BASELINE.json's metric; src/inference/metrics.py:386-405 on a parameter subset): per-chain ESS of
     # each selected parameter, summed over chains, min / median over the subset, per second of `time.sampling`
     from mile_amd.metrics import effective_sample_size

@@ -73,6 +73,10 @@ typedef enum mile_grad_kernel {
                                      three-term bf16 products, bias / activation / activation-derivative fused into their
                                      epilogues; what AUTO picks for wide nets (hidden width >= 96: B4's 4 x 256 softmax net) */
   MILE_GRAD_MFMA_WIDE_BF16 = 8,   /* the same kernels with bf16-ROUNDED operands (one product instead of six); explicit only */
+  MILE_GRAD_MFMA_NARROW_F32 = 10, /* FCNs with 1-3 hidden layers of width <= 32, F <= 64 inputs, <= 16 outputs, any activation,
+                                     either head: fused forward + backward on v_mfma_f32_16x16x4_f32 (fp32 operands -- exact fp32
+                                     products, fp32 accumulation); what AUTO picks for the reference's own 16- / 32-wide nets
+                                     (experiments/replicate_uci/mclmc.yaml [16,16,2], tabluar_classif/covertype.yaml [32,7]) */
   MILE_GRAD_LENET_BF16 = 9        /* MILE_MODEL_LENET, <= 4 image channels: the five convolution products as implicit GEMMs on
                                      v_mfma_f32_16x16x32_bf16 with bf16-ROUNDED operands (BASELINE config 5 names bf16), the rest
                                      as LENET_F32; explicit only */
@@ -182,7 +186,7 @@ int32_t mile_set_data(mile_sampler *s, const float *X, const void *y, int64_t N,
 /* Restrict the likelihood to rows [begin, begin + count) of the training set for the following mile_logpost_grad calls
  * (count = 0: all rows again).  Replaces the minibatches of the warm-start stage: loader.iter(split='train', batch_size=...)
  * (src/dataset/tabular.py:170-212) feeding single_step_regr / single_step_class (src/training/trainer.py:706-760).
- * Supported by MILE_GRAD_GENERIC, the MFMA_W64, MFMA_WIDE and LENET kernels (mile_logpost_grad fails with MILE_ERR_STATE on
+ * Supported by MILE_GRAD_GENERIC, the MFMA_NARROW, MFMA_W64, MFMA_WIDE and LENET kernels (mile_logpost_grad fails with MILE_ERR_STATE on
  * MFMA_W128_BF16 / GEMM_F32 under a window); the MCLMC path itself is full-batch (n_batches = 1). */
 int32_t mile_set_row_window(mile_sampler *s, int64_t begin, int64_t count);
 

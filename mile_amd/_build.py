@@ -17,7 +17,7 @@ LIB_PATH = PKG_DIR / 'libmile_hip.so'
 # mile_w64_fq2.hip is built without it (hipcc 7.2 crashes on k_grad_w64<3,2,true> with it).
 VGPR_FORM = ['-mllvm', '-amdgpu-mfma-vgpr-form']
 SOURCES = {'mile_hip.hip': VGPR_FORM, 'mile_w64_fq2.hip': []}
-HEADERS = ['mile_device.h', 'mile_grad_generic.h', 'mile_grad_w64.h', 'mile_grad_w64_block.inc', 'mile_bf16_frag.h',
+HEADERS = ['mile_device.h', 'mile_grad_generic.h', 'mile_grad_narrow.h', 'mile_grad_w64.h', 'mile_grad_w64_block.inc', 'mile_bf16_frag.h',
            'mile_grad_w128b.h', 'mile_grad_gemm.h', 'mile_mm3.h', 'mile_lenet.h', 'mile_lenet_mfma.h', 'mile_predict.h', 'mile_update.h']
 OBJ_DIR = PKG_DIR / 'csrc' / '_obj'
 

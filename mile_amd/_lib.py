@@ -14,7 +14,7 @@ TASK_IDS = {'regr': 0, 'regression': 0, 'classification': 1, 'class': 1}
 PRIOR_IDS = {'Normal': 0, 'StandardNormal': 0, 'Laplace': 1}
 REFRESH_IDS = {'O-step-O': 0, 'step-O': 1}
 GRAD_KERNEL_IDS = {'auto': 0, 'generic': 1, 'mfma_w64': 2, 'mfma_w128_bf16': 3, 'gemm_f32': 4, 'lenet_f32': 5, 'mfma_w64_bf16x3': 6,
-                   'mfma_wide_bf16x3': 7, 'mfma_wide_bf16': 8, 'lenet_bf16': 9}
+                   'mfma_wide_bf16x3': 7, 'mfma_wide_bf16': 8, 'lenet_bf16': 9, 'mfma_narrow_f32': 10}
 
 
 class ModelSpecC(C.Structure):

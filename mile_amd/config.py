@@ -164,7 +164,7 @@ class SamplerConfig:
     def __post_init__(self):
         _check(self.name in ('nuts', 'mclmc', 'hmc', 'mclmc_hip'), f'unknown sampler {self.name!r}')
         _check(self.grad_kernel in ('auto', 'generic', 'mfma_w64', 'mfma_w64_bf16x3', 'mfma_w128_bf16', 'gemm_f32', 'mfma_wide_bf16x3',
-                                    'mfma_wide_bf16', 'lenet_f32', 'lenet_bf16'), f'unknown grad_kernel {self.grad_kernel!r}')
+                                    'mfma_wide_bf16', 'lenet_f32', 'lenet_bf16', 'mfma_narrow_f32'), f'unknown grad_kernel {self.grad_kernel!r}')
 
     @property
     def prior(self) -> Prior:

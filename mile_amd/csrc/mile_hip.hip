@@ -14,6 +14,7 @@
 
 #include "mile_device.h"
 #include "mile_grad_generic.h"
+#include "mile_grad_narrow.h"
 #include "mile_grad_w64.h"
 #include "mile_grad_w128b.h"
 #include "mile_grad_gemm.h"
@@ -87,6 +88,18 @@ static bool w64_supported(const mile_model_spec &sp) {
 }
 
 // the split-bf16 variant replaces the hidden->hidden products, so it needs at least one
+// k_grad_narrow: 1-3 hidden layers of width <= 32, F <= 64, <= 16 outputs (regression: exactly mu, log sigma), any activation
+static bool narrow_supported(const mile_model_spec &sp) {
+  if (sp.model != MILE_MODEL_FCN || !sp.use_bias) return false;
+  const int nh = sp.n_layers - 1;
+  if (nh < 1 || nh > 3 || sp.in_features > 64) return false;
+  for (int l = 0; l < nh; ++l)
+    if (sp.widths[l] < 1 || sp.widths[l] > 32) return false;
+  const int K = sp.widths[nh];
+  if (K < 1 || K > 16) return false;
+  if (sp.task == MILE_TASK_REGRESSION && K != 2) return false;
+  return true;
+}
 static bool w64x3_supported(const mile_model_spec &sp) { return w64_supported(sp) && sp.n_layers - 1 >= 2; }
 static bool is_w64(int kernel) { return kernel == MILE_GRAD_MFMA_W64 || kernel == MILE_GRAD_MFMA_W64_BF16X3; }
 
@@ -148,7 +161,10 @@ static int resolved_kernel(const mile_sampler *s) {
     if (w64x3_supported(s->spec)) return MILE_GRAD_MFMA_W64_BF16X3;   // fp32-faithful and never slower than MFMA_W64
     if (w64_supported(s->spec)) return MILE_GRAD_MFMA_W64;
     // wide nets: the hand-written layer-wise MFMA GEMMs (fp32-faithful); rocBLAS (GEMM_F32) is the cross-check, never AUTO
-    return gemm_preferred(s->spec) ? MILE_GRAD_MFMA_WIDE_BF16X3 : MILE_GRAD_GENERIC;
+    if (gemm_preferred(s->spec)) return MILE_GRAD_MFMA_WIDE_BF16X3;
+    // the reference's own nets (16 / 32 wide, any activation, either head): fused fp32-MFMA kernel
+    if (narrow_supported(s->spec) && getenv("MILE_NO_NARROW") == nullptr) return MILE_GRAD_MFMA_NARROW_F32;
+    return MILE_GRAD_GENERIC;
   }
   return s->grad_kernel;
 }
@@ -161,7 +177,20 @@ static int generic_R(const DevSpec &ds) {
   return R;
 }
 
+// k_grad_narrow: 16-row tiles, 1-4 waves per workgroup; enough workgroups to put ~2 waves on every SIMD of the chip even for
+// a dozen chains (E = 12, N = 1052: 66 tiles per particle -> S = 64 one-/two-wave workgroups each)
+static int narrow_S(const mile_sampler *s, int E) {
+  const int tiles = (s->N + 15) / 16;
+  int S = (8 * s->n_cu + std::max(E, 1) - 1) / std::max(E, 1);
+  return std::max(1, std::min({S, 64, tiles}));
+}
+static int narrow_waves(const mile_sampler *s, int S, int N) {
+  const int tiles = (N + 15) / 16;
+  return std::max(1, std::min(NRW_MAXW, (tiles + S - 1) / S));
+}
+
 static int choose_S(const mile_sampler *s, int E, int kernel) {
+  if (kernel == MILE_GRAD_MFMA_NARROW_F32) return narrow_S(s, E);
   if (is_w64(kernel)) {
     const int NB = s->Npad / 32;
     int S = std::max(1, s->n_cu / std::max(E, 1));
@@ -370,16 +399,24 @@ int32_t mile_set_data(mile_sampler *s, const float *X, const void *y, int64_t N,
   if (N < 1 || N > 0x3fffffff) return fail(MILE_ERR_INVALID, "mile_set_data: N out of range");
   hipStream_t st = (hipStream_t)stream;
   HIP_TRY(hipSetDevice(s->device));
-  free_data(s);
-  free_ws(s);
   const int F = s->spec.in_features;
+  // Same number of rows as before (the warm-start stage hands over a reshuffled copy of the training set every epoch,
+  // src/dataset/tabular.py:170-212): every buffer and the workspace keep their sizes -- overwrite in place, no
+  // free / malloc cycle of ~15 allocations per epoch.
+  const bool same_shape = s->X && s->N == (int)N;
+  if (!same_shape) {
+    free_data(s);
+    free_ws(s);
+  }
   s->N = (int)N;
   s->Npad = ((int)N + 31) / 32 * 32;
   s->Fp = (F + 7) / 8 * 8;
-  HIP_TRY(hipMalloc(&s->X, (size_t)N * F * 4));
-  // (32 rows of slack: a row window that ends at the last row still reads whole 32-row blocks from its own first row)
-  HIP_TRY(hipMalloc(&s->Xp, (size_t)(s->Npad + 32) * s->Fp * 4));
-  HIP_TRY(hipMalloc(&s->y, (size_t)(s->Npad + 32) * 4));
+  if (!same_shape) {
+    HIP_TRY(hipMalloc(&s->X, (size_t)N * F * 4));
+    // (32 rows of slack: a row window that ends at the last row still reads whole 32-row blocks from its own first row)
+    HIP_TRY(hipMalloc(&s->Xp, (size_t)(s->Npad + 32) * s->Fp * 4));
+    HIP_TRY(hipMalloc(&s->y, (size_t)(s->Npad + 32) * 4));
+  }
   HIP_TRY(hipMemsetAsync(s->Xp, 0, (size_t)(s->Npad + 32) * s->Fp * 4, st));
   HIP_TRY(hipMemcpyAsync(s->X, X, (size_t)N * F * 4, hipMemcpyDeviceToDevice, st));
   HIP_TRY(hipMemsetAsync(s->y, 0, (size_t)(s->Npad + 32) * 4, st));
@@ -390,8 +427,10 @@ int32_t mile_set_data(mile_sampler *s, const float *X, const void *y, int64_t N,
   HIP_TRY(hipGetLastError());
   if (w128b_supported(s->spec)) {
     s->Npb = ((int)N + 63) / 64 * 64;
-    HIP_TRY(hipMalloc(&s->Xb, (size_t)s->Npb * 16 * 2));
-    HIP_TRY(hipMalloc(&s->Xt, (size_t)s->Npb * 32 * 2));
+    if (!same_shape) {
+      HIP_TRY(hipMalloc(&s->Xb, (size_t)s->Npb * 16 * 2));
+      HIP_TRY(hipMalloc(&s->Xt, (size_t)s->Npb * 32 * 2));
+    }
     const long long tb = (long long)s->Npb * 32;
     k_prep_bf16<<<(unsigned)((tb + 255) / 256), 256, 0, st>>>(s->X, (bf16 *)s->Xb, (bf16 *)s->Xt, s->N, s->Npb, F);
     HIP_TRY(hipGetLastError());
@@ -415,6 +454,7 @@ int32_t mile_reserve(mile_sampler *s, int32_t E) {
   // capacity must cover whichever grad kernel is selected later
   int S = std::max(choose_S(s, E, MILE_GRAD_GENERIC), w64_supported(s->spec) ? choose_S(s, E, MILE_GRAD_MFMA_W64) : 1);
   if (w128b_supported(s->spec)) S = std::max(S, choose_S(s, E, MILE_GRAD_MFMA_W128_BF16));
+  if (narrow_supported(s->spec)) S = std::max(S, choose_S(s, E, MILE_GRAD_MFMA_NARROW_F32));
   // A smaller ensemble splits the rows of a particle over MORE workgroups (S grows as E shrinks): capacity is counted in
   // slab rows E * S, and a later call with fewer particles must neither fail nor shrink what a larger one reserved.
   if (E <= s->E_cap && (size_t)E * S <= s->ES_cap) return MILE_OK;
@@ -439,7 +479,9 @@ int32_t mile_reserve(mile_sampler *s, int32_t E) {
 
 int32_t mile_set_grad_kernel(mile_sampler *s, int32_t which) {
   if (!s) return fail(MILE_ERR_INVALID, "null handle");
-  if (which < MILE_GRAD_AUTO || which > MILE_GRAD_LENET_BF16) return fail(MILE_ERR_INVALID, "unknown grad kernel");
+  if (which < MILE_GRAD_AUTO || which > MILE_GRAD_MFMA_NARROW_F32) return fail(MILE_ERR_INVALID, "unknown grad kernel");
+  if (which == MILE_GRAD_MFMA_NARROW_F32 && !narrow_supported(s->spec))
+    return fail(MILE_ERR_INVALID, "MFMA_NARROW_F32 needs an FCN with 1-3 hidden layers of width <= 32, F <= 64 and <= 16 outputs");
   if ((which == MILE_GRAD_MFMA_WIDE_BF16X3 || which == MILE_GRAD_MFMA_WIDE_BF16) && s->spec.model != MILE_MODEL_FCN)
     return fail(MILE_ERR_INVALID, "MFMA_WIDE_* are FCN kernels");
   if ((s->spec.model == MILE_MODEL_LENET) != (which == MILE_GRAD_LENET_F32 || which == MILE_GRAD_LENET_BF16) && which != MILE_GRAD_AUTO)
@@ -603,6 +645,26 @@ static bool fuse_ok(const mile_sampler *s, int kernel, const UpdParams &u) {
   for (const void *q : ptrs)
     if (q && ptr_align(q) < 2) return false;
   return true;
+}
+
+template <int NH, int TH, int TF>
+static hipError_t launch_narrow_t(const GradParams &gp, int E, int nw, hipStream_t st) {
+  using LY = NarrowLayout<NH, TH, TF>;
+  k_grad_narrow<NH, TH, TF><<<dim3(gp.S, E), 64 * nw, LY::BYTES, st>>>(gp);
+  return hipGetLastError();
+}
+static hipError_t launch_narrow(const mile_sampler *s, const GradParams &gp, int E, hipStream_t st) {
+  const int nh = s->spec.n_layers - 1;
+  int mw = 0;
+  for (int l = 0; l < nh; ++l) mw = std::max(mw, s->spec.widths[l]);
+  const int th = mw <= 16 ? 1 : 2, tf = s->spec.in_features <= 16 ? 1 : 4;
+  const int nw = narrow_waves(s, gp.S, gp.N);
+#define MILE_NRW(NH_, TH_, TF_) if (nh == NH_ && th == TH_ && tf == TF_) return launch_narrow_t<NH_, TH_, TF_>(gp, E, nw, st);
+  MILE_NRW(1, 1, 1) MILE_NRW(1, 2, 1) MILE_NRW(1, 1, 4) MILE_NRW(1, 2, 4)
+  MILE_NRW(2, 1, 1) MILE_NRW(2, 2, 1) MILE_NRW(2, 1, 4) MILE_NRW(2, 2, 4)
+  MILE_NRW(3, 1, 1) MILE_NRW(3, 2, 1) MILE_NRW(3, 1, 4) MILE_NRW(3, 2, 4)
+#undef MILE_NRW
+  return hipErrorInvalidValue;
 }
 
 template <int NH>
@@ -1271,8 +1333,8 @@ static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t s
   if (s->win_count) {   // minibatch: the same kernels on a shifted view of the rows
     const bool chunked = kernel == MILE_GRAD_MFMA_WIDE_BF16X3 || kernel == MILE_GRAD_MFMA_WIDE_BF16 || kernel == MILE_GRAD_LENET_F32 ||
                          kernel == MILE_GRAD_LENET_BF16;   // these walk the rows in chunks anyway: a window is a shorter walk
-    if (kernel != MILE_GRAD_GENERIC && !is_w64(kernel) && !chunked)
-      return fail(MILE_ERR_STATE, "a row window needs the generic, an MFMA_W64, an MFMA_WIDE or a LENET grad kernel");
+    if (kernel != MILE_GRAD_GENERIC && kernel != MILE_GRAD_MFMA_NARROW_F32 && !is_w64(kernel) && !chunked)
+      return fail(MILE_ERR_STATE, "a row window needs the generic, the MFMA_NARROW, an MFMA_W64, an MFMA_WIDE or a LENET grad kernel");
     if (fused_update) return fail(MILE_ERR_STATE, "row windows are for mile_logpost_grad only");
     const int F = s->spec.in_features;
     gp.X = s->X + (size_t)s->win_begin * F;
@@ -1321,6 +1383,8 @@ static int launch_grad(mile_sampler *s, const float *theta, int E, hipStream_t s
     else if (nh == 3 && fq == 1) e = launch_w64<3, 1, true>(gp, fz, E, st);
     else if (fq == 2 && !fz.enabled) e = mile_launch_w64_split_fq2(nh, gp, E, st);   // mile_w64_fq2.hip
     HIP_TRY(e);
+  } else if (kernel == MILE_GRAD_MFMA_NARROW_F32) {
+    HIP_TRY(launch_narrow(s, gp, E, st));
   } else if (kernel == MILE_GRAD_LENET_F32 || kernel == MILE_GRAD_LENET_BF16) {
     const int rc = run_lenet(s, theta, E, gp.X, gp.y, gp.N, gp.slabs, gp.dp, gp.llpart, nullptr, 0, st, kernel == MILE_GRAD_LENET_BF16);
     if (rc) return rc;
@@ -1591,6 +1655,10 @@ int32_t mile_grad_launch_info(const mile_sampler *s, int32_t E, int32_t *grid_x,
     nm = "k_grad_w64";
     lds = nh == 2 ? (fq == 1 ? w64_lds_bytes<2, 1, true>() : w64_lds_bytes<2, 2, true>())
                   : (fq == 1 ? w64_lds_bytes<3, 1, true>() : w64_lds_bytes<3, 2, true>());
+  } else if (kernel == MILE_GRAD_MFMA_NARROW_F32) {
+    nm = "k_grad_narrow";
+    if (block) *block = 64 * narrow_waves(s, S, s->N);
+    lds = NarrowLayout<3, 2, 4>::BYTES;   // upper bound over the instantiations
   } else if (kernel == MILE_GRAD_LENET_BF16) {
     nm = "k_conv5m_fwd/dx/dw (implicit-GEMM bf16 MFMA) + k_mm3 (Dense, fp32-faithful three-term products)";
     lds = (int)cm_lds_dw(CM_IN8, s->lg.hp1, s->lg.wp1, 0);

@@ -113,8 +113,9 @@ class Engine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.mile_set_data(self._h, _ptr(X), _ptr(y), X.shape[0], self._stream()), self.lib)
             torch.cuda.current_stream(self.device).synchronize()   # X, y may be temporaries
+        if int(X.shape[0]) != getattr(self, 'N', None):
+            self._E_reserved = 0            # (same N: the library keeps its buffers and workspace)
         self.N = int(X.shape[0])
-        self._E_reserved = 0
 
     def set_row_window(self, begin: int = 0, count: int = 0):
         """Likelihood over rows [begin, begin + count) of the training set for the following logpost_grad calls

@@ -8,13 +8,13 @@ from the HIP engine: the epoch's shuffled copy of the training set is handed to 
 optimizer step evaluates the members on one contiguous row window of it (`mile_set_row_window`: the generic, width-64
 MFMA, layer-wise wide-net and LeNet kernels) -- the reference's batches, optimizer, validation schedule and
 early-stopping rule; only the permutation differs (torch's generator instead of JAX's key).  The two kernels without a
-row window (the rocBLAS cross-check path and the width-128 bf16 kernel) fall back to the same number of FULL-batch
-steps per epoch (documented deviation).
+row window (the rocBLAS cross-check path and the width-128 bf16 kernel) are swapped for the kernel AUTO picks for the
+net while the members are trained (round 3; before: the same number of FULL-batch steps per epoch), and come back for
+sampling.
 """
 from __future__ import annotations
 
 import logging
-import math
 
 import torch
 
@@ -81,14 +81,23 @@ def train_deep_ensemble(eng, prior, theta0: torch.Tensor, n_train: int, valid_x,
     theta = theta0.to(dev, torch.float32).clone()
     E = theta.shape[0]
     opt = _Optimizer(optimizer, optimizer_parameters or {}, theta)
-    minibatch = bool(batch_size) and batch_size < n_train and train_x is not None and train_y is not None and \
-        eng.grad_kernel in ('generic', 'mfma_w64', 'mfma_w64_bf16x3', 'mfma_wide_bf16x3', 'mfma_wide_bf16', 'lenet_f32', 'lenet_bf16')
+    WINDOWED = ('generic', 'mfma_narrow_f32', 'mfma_w64', 'mfma_w64_bf16x3', 'mfma_wide_bf16x3', 'mfma_wide_bf16', 'lenet_f32', 'lenet_bf16')
+    want_minibatch = bool(batch_size) and batch_size < n_train and train_x is not None and train_y is not None
+    sampler_kernel = eng.grad_kernel
+    if want_minibatch and sampler_kernel not in WINDOWED:
+        # the sampler's kernel has no row window (width-128 bf16, rocBLAS cross-check): train on what AUTO picks for this net
+        # (fp32-faithful, windowed) and hand the engine back as configured -- the reference's minibatches rather than the same
+        # number of full-batch steps
+        eng.set_grad_kernel('auto')
+        if eng.grad_kernel not in WINDOWED:
+            eng.set_grad_kernel(sampler_kernel)
+    minibatch = want_minibatch and eng.grad_kernel in WINDOWED
     if minibatch:
         n_batches = n_train // batch_size                                    # drop last, tabular.py:190-191
         gen = torch.Generator().manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
         tx = torch.as_tensor(train_x).reshape(n_train, -1)
         ty = torch.as_tensor(train_y)
-    steps_per_epoch = 1 if not batch_size else max(1, math.ceil(n_train / batch_size))
+    steps_per_epoch = 1 if not batch_size else max(1, n_train // batch_size)      # len // batch_size, tabular.py:190-191
     has_valid = valid_x is not None and len(valid_x) > 0
     stopped = torch.zeros(E, dtype=torch.bool, device=dev)
     hist_valid = torch.empty((E, 0), device=dev)
@@ -125,6 +134,8 @@ def train_deep_ensemble(eng, prior, theta0: torch.Tensor, n_train: int, valid_x,
     finally:
         if minibatch:                                                        # the sampler wants the full set, original order
             eng.set_data(tx, ty)
+        if eng.grad_kernel != sampler_kernel:
+            eng.set_grad_kernel(sampler_kernel)
     hist = {'epochs': epoch + 1, 'valid_nll': hist_valid.cpu(), 'train_nll': None if train_nll is None else train_nll.cpu(),
             'stopped': stopped.cpu(), 'minibatch': minibatch}
     return theta, hist

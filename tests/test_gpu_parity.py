@@ -30,9 +30,22 @@ CASES = [
     (5, (64, 64, 64, 2), 'relu', 'regr', 'Normal', 100, 3, ('generic', 'mfma_w64', 'mfma_w64_bf16x3')),
     (5, (64, 64, 2), 'relu', 'regr', 'Normal', 333, 5, ('generic', 'mfma_w64', 'mfma_w64_bf16x3', 'gemm_f32', 'mfma_wide_bf16x3')),
     (8, (64, 2), 'relu', 'regr', 'Laplace', 64, 2, ('generic', 'mfma_w64')),
-    (5, (16, 16, 2), 'relu', 'regr', 'Normal', 1052, 12, ('generic',)),
-    (9, (24, 17, 2), 'tanh', 'regr', 'Normal', 257, 4, ('generic', 'gemm_f32', 'mfma_wide_bf16x3')),
-    (11, (32, 7), 'sigmoid', 'classification', 'Normal', 500, 6, ('generic', 'gemm_f32', 'mfma_wide_bf16x3')),
+    (5, (16, 16, 2), 'relu', 'regr', 'Normal', 1052, 12, ('generic', 'mfma_narrow_f32', 'auto')),      # the reference's stock net
+    (9, (24, 17, 2), 'tanh', 'regr', 'Normal', 257, 4, ('generic', 'gemm_f32', 'mfma_wide_bf16x3', 'mfma_narrow_f32')),
+    (11, (32, 7), 'sigmoid', 'classification', 'Normal', 500, 6, ('generic', 'gemm_f32', 'mfma_wide_bf16x3', 'mfma_narrow_f32')),
+    # round 3: k_grad_narrow (fp32 MFMA 16x16x4, what AUTO picks for hidden widths <= 32): the reference's real nets --
+    # covertype [54 -> 32 -> 7] sigmoid, README / protein [16,16,16,2] -- every template form (1-3 hidden layers, one or two
+    # 16-wide tiles per hidden layer, F <= 16 or <= 64), ragged widths, tanh, both heads, 16 classes, tiles vs workgroups
+    (54, (32, 7), 'sigmoid', 'classification', 'Normal', 700, 5, ('generic', 'mfma_narrow_f32', 'auto')),
+    (5, (16, 16, 16, 2), 'relu', 'regr', 'Normal', 1052, 12, ('generic', 'mfma_narrow_f32')),
+    (9, (16, 16, 16, 2), 'relu', 'regr', 'Laplace', 333, 3, ('generic', 'mfma_narrow_f32')),
+    (20, (32, 32, 32, 5), 'tanh', 'classification', 'Normal', 130, 2, ('generic', 'mfma_narrow_f32')),
+    (64, (9, 30, 16), 'relu', 'classification', 'Normal', 97, 3, ('generic', 'mfma_narrow_f32')),
+    (17, (5, 2), 'sigmoid', 'regr', 'Normal', 40, 1, ('generic', 'mfma_narrow_f32')),
+    (3, (1, 1, 2), 'tanh', 'regr', 'Normal', 33, 2, ('generic', 'mfma_narrow_f32')),
+    (5, (16, 16, 2), 'relu', 'regr', 'Normal', 2, 1, ('generic', 'mfma_narrow_f32')),
+    (5, (16, 16, 2), 'relu', 'regr', 'Normal', 17, 300, ('generic', 'mfma_narrow_f32')),
+    (16, (32, 16, 3), 'relu', 'classification', 'Normal', 4099, 2, ('generic', 'mfma_narrow_f32')),
     (54, (40, 40, 7), 'relu', 'classification', 'Laplace', 130, 3, ('generic', 'gemm_f32', 'mfma_wide_bf16x3')),
     # wide nets: the layer-wise paths -- hand-written MFMA GEMMs (what AUTO picks there) and rocBLAS (the cross-check) --
     # B3- and B4-shaped, and shapes that leave ragged 128 x 128 x 64 tiles in every dimension
@@ -75,7 +88,8 @@ def test_logpost_grad_matches_oracle(oracle, F, hs, act, task, prior, N, E, kern
     lp_ref, g_ref = oracle.logpost_and_grad(ospec, prob['theta0'].astype(np.float64), prob['X'], prob['y'])
     for k in kernels:
         eng = _engine(oracle, ospec, prob, k)
-        assert eng.grad_kernel == (k if k != 'auto' else 'mfma_wide_bf16x3')
+        wide = max(hs[:-1], default=0) >= 96
+        assert eng.grad_kernel == (k if k != 'auto' else ('mfma_wide_bf16x3' if wide else 'mfma_narrow_f32'))
         lp, g = eng.logpost_grad(torch.from_numpy(prob['theta0']))
         torch.cuda.synchronize()
         # fp32 accumulation over N rows vs fp64: tolerance 2e-5 relative to the largest entry

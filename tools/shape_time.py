@@ -1,5 +1,5 @@
 """Time mile_logpost_grad on an arbitrary FCN shape.  Dev tool.
-usage: python tools/shape_time.py F h1,h2,..,out task N E kernel[,kernel...] [reps]"""
+usage: python tools/shape_time.py F h1,h2,..,out task N E kernel[,kernel...] [reps] [activation]"""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -9,7 +9,8 @@ from mile_amd.engine import Engine
 
 F = int(sys.argv[1]); hs = tuple(int(v) for v in sys.argv[2].split(',')); task = sys.argv[3]
 N = int(sys.argv[4]); E = int(sys.argv[5]); kernels = sys.argv[6].split(','); reps = int(sys.argv[7]) if len(sys.argv) > 7 else 5
-spec = ModelSpec(F, hs, task=task)
+act = sys.argv[8] if len(sys.argv) > 8 else 'relu'
+spec = ModelSpec(F, hs, task=task, activation=act)
 d = spec.n_params
 fin, W = F, 0
 for w in hs:
