@@ -1232,6 +1232,16 @@ static int launch_grad_wide(mile_sampler *s, const GradParams &gp, int E, hipStr
     tmp[0] = q; q += (size_t)E * R * maxwp;
     tmp[1] = q;
   }
+  // The two dZ buffers are shared by layers of different padded widths: a layer's padding columns (real width .. wp) are not
+  // written by the dH epilogue and would otherwise show what an earlier use with another leading dimension -- possibly an
+  // earlier CALL with a diverged, non-finite theta -- left there; k_mm3 reads operands in 4- / 8-element granules, and
+  // NaN x 0 is NaN.  Re-zeroed per call whenever the hidden layers pad to different widths (nets of equal hidden
+  // widths -- B4 -- keep one layout per buffer, whose padding stays zero from the workspace's own memset).
+  {
+    bool mixed = false;                                    // dZ of layers 0 .. L-2 lives in tmp with leading dimension wp[l]
+    for (int l = 1; l + 1 < L; ++l) mixed = mixed || wp[l] != wp[0];
+    if (mixed) HIP_TRY(hipMemsetAsync(tmp[0], 0, (size_t)E * R * maxwp * 2 * 4, st));
+  }
   bf16 *Wt = (bf16 *)s->wide_wt;
   // ---- this gradient's weights as zero-padded bf16 term planes [E][layer][term][in][outp]
   for (int l = 0; l < L; ++l) {

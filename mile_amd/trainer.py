@@ -53,9 +53,18 @@ class BDETrainer:
         # exists); every other rank must derive its paths from THAT name, or it writes into the previous run.
         if self.world_size > 1:
             mdist.init_process_group()
-            name = [config.setup_dir().experiment_name if self.rank == 0 else None]
-            mdist.broadcast_object(name)
-            self.config = config.replace(experiment_name=name[0])
+            # rank 0 broadcasts (name, error): if its setup_dir() fails the other ranks must not wait in the broadcast forever
+            msg = [None]
+            if self.rank == 0:
+                try:
+                    msg = [(config.setup_dir().experiment_name, None)]
+                except Exception as exc:                      # noqa: BLE001 -- re-raised below, on every rank
+                    msg = [(None, f'{type(exc).__name__}: {exc}')]
+            mdist.broadcast_object(msg)
+            name, err = msg[0]
+            if err is not None:
+                raise RuntimeError(f'rank 0 could not set up the experiment directory: {err}')
+            self.config = config.replace(experiment_name=name)
         else:
             self.config = config.setup_dir()
         self._key = PRNGKey(config.rng)
@@ -174,9 +183,13 @@ class BDETrainer:
                 y = torch.from_numpy(np.ascontiguousarray(self.loader.train_y))
             log_post = self.prob_model.bind(x, y)
             for step in self.train_plan:
-                if len(step) < self.world_size:        # every rank takes part in the per-group collectives
-                    raise ValueError(f'a chain group of {len(step)} chains cannot be sharded over {self.world_size} ranks')
                 mine = mdist.shard_chains(step, self.world_size, self.rank)
+                if len(mine) == 0:
+                    # fewer chains in the group than ranks (4 chains on 8 GPUs): this rank has nothing to sample but still
+                    # joins the group's one collective -- the gather of the tuned (step_size, L) for warmup_params.txt
+                    logger.info('\t| No chain of this group on this rank')
+                    mdist.gather_objects((np.zeros(0, np.float32), np.zeros(0, np.float32)))
+                    continue
                 logger.info(f'\t| Starting Sampling for chains {mine}')
                 if chains:
                     params = load_params_batch([chains[i] for i in mine], self.prob_model.spec)

@@ -768,7 +768,11 @@ def test_train_cli_classification_wide_net(tmp_path):
 
 LPPD_GATE_CASES = [
     # in_features, hidden, activation, task, N, E, T, step-size factor, grad kernel the engine must resolve to
-    (5, (16, 16, 2), 'relu', 'regr', 200, 4, 60, 3.0, 'generic'),
+    # the reference's stock net shape on the kernel AUTO selects for it (round 3: k_grad_narrow), a sigmoid softmax net on the
+    # same kernel, and a width only the generic kernel covers
+    (5, (16, 16, 2), 'relu', 'regr', 200, 4, 60, 3.0, 'mfma_narrow_f32'),
+    (54, (32, 7), 'sigmoid', 'classification', 400, 4, 60, 1.0, 'mfma_narrow_f32'),
+    (5, (40, 40, 2), 'relu', 'regr', 200, 4, 60, 3.0, 'generic'),
     # BASELINE config B1 (airfoil shape, 3x64 MLP, 16 particles) on the kernel AUTO selects
     (5, (64, 64, 64, 2), 'relu', 'regr', 1052, 16, 120, 1.0, 'mfma_w64_bf16x3'),
     # the layer-wise MFMA GEMM path on a small softmax net (B4's head)
@@ -780,7 +784,8 @@ LPPD_GATE_CASES = [
 def test_lppd_matches_oracle_after_equal_step_count(oracle, F, hs, act, task, N, E, T, eps_mul, kernel):
     """The +-1 % LPPD gate of BASELINE.json: the device sampler and the fp64 oracle run the same number of steps from
     the same state on the SAME noise; the LPPD of their kept samples on held-out rows must agree within 1 %.
-    Every production grad kernel family has a case: generic, the AUTO kernel at the B1 shape, the GEMM path."""
+    Every production grad kernel family has a case: the narrow-net kernel (both heads), generic, the AUTO kernel at the B1
+    shape, the GEMM path."""
     from mile_amd.metrics import lppd
     ospec = oracle.ModelSpec(F, hs, activation=act, task=task)
     thin, Nt = 5, 77

@@ -97,6 +97,29 @@ def test_logpost_grad_matches_oracle(oracle, F, hs, act, task, prior, N, E, kern
         assert _relerr(g.cpu().numpy(), g_ref) < 2e-5, k
 
 
+def test_wide_path_is_not_poisoned_by_a_previous_non_finite_call(oracle):
+    """launch_grad_wide shares two dZ buffers between layers of different padded widths (hidden widths that are
+    not multiples of 8 and differ: 100 / 50 / 20 -> leading dimensions 104 / 56 / 24).  A layer's padding columns are not
+    written by the dH epilogue, k_mm3 reads operands in 4- / 8-element granules, and a NaN a diverged call left in what is
+    now padding would turn into NaN x 0 = NaN.  Two consecutive gradients on one engine, the first at a non-finite theta:
+    the second must equal a fresh engine's (and the fp64 oracle's)."""
+    ospec = oracle.ModelSpec(13, (100, 50, 20, 3), activation='tanh', task='classification')
+    prob = oracle.synthetic_problem(ospec, 300, 3, seed=5)
+    th = torch.from_numpy(prob['theta0'])
+    bad = th.clone()
+    bad[:] = float('nan')
+    eng = _engine(oracle, ospec, prob, 'mfma_wide_bf16x3')
+    lp_bad, g_bad = eng.logpost_grad(bad)
+    assert not torch.isfinite(g_bad).any()
+    lp, g = eng.logpost_grad(th)
+    torch.cuda.synchronize()
+    lp_ref, g_ref = oracle.logpost_and_grad(ospec, prob['theta0'].astype(np.float64), prob['X'], prob['y'])
+    assert torch.isfinite(g).all() and torch.isfinite(lp).all()
+    assert _relerr(lp.cpu().numpy(), lp_ref) < 2e-5 and _relerr(g.cpu().numpy(), g_ref) < 2e-5
+    fresh = _engine(oracle, ospec, prob, 'mfma_wide_bf16x3').logpost_grad(th)
+    assert torch.equal(fresh[1], g) and torch.equal(fresh[0], lp)
+
+
 @pytest.mark.parametrize('F,hs,N,E', [(5, (64, 64, 64, 2), 1052, 32), (12, (64, 64, 2), 777, 9), (5, (64, 64, 2), 64, 300)])
 def test_split_bf16_w64_kernel_is_fp32_faithful(oracle, F, hs, N, E):
     """mfma_w64_bf16x3 (what AUTO picks for 2-3 hidden layers of width 64) forms each fp32 product exactly from
