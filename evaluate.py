@@ -116,7 +116,7 @@ def main():
                     'ess_per_s_min': float(np.nanmin(ess) / t_sampling) if t_sampling else None,
                     'ess_per_s_median': float(np.nanmedian(ess) / t_sampling) if t_sampling else None})
     (exp / 'metrics.json').write_text(json.dumps(out, indent=1) + '\n')
-    print(json.dumps(out))
+    print(json.dumps({k: v for k, v in out.items() if not isinstance(v, list)}))        # the per-chain arrays stay in metrics.json
 
 
 if __name__ == '__main__':

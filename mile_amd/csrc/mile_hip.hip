@@ -177,12 +177,14 @@ static int generic_R(const DevSpec &ds) {
   return R;
 }
 
-// k_grad_narrow: 16-row tiles, 1-4 waves per workgroup; enough workgroups to put ~2 waves on every SIMD of the chip even for
-// a dozen chains (E = 12, N = 1052: 66 tiles per particle -> S = 64 one-/two-wave workgroups each)
+// k_grad_narrow: 16-row tiles, workgroups of up to 4 waves.  About two waves per SIMD over the whole grid (8 x CUs waves) and
+// NO MORE row splits than that needs: every split is one more slab the update kernels sum -- with S = 64 splits of a d = 402
+// net the two update launches of a step took 27-31 us each against 6.8 us for the gradient itself (profiles/r03/12_*), the
+// slab / llpart loops being 64 dependent global loads long.  E = 12, N = 1052 (66 tiles): 17 splits of 4 waves; E = 128: 4.
 static int narrow_S(const mile_sampler *s, int E) {
   const int tiles = (s->N + 15) / 16;
-  int S = (8 * s->n_cu + std::max(E, 1) - 1) / std::max(E, 1);
-  return std::max(1, std::min({S, 64, tiles}));
+  const int waves_per_particle = std::max(1, std::min(tiles, (8 * s->n_cu + std::max(E, 1) - 1) / std::max(E, 1)));
+  return std::max(1, std::min(64, (waves_per_particle + NRW_MAXW - 1) / NRW_MAXW));
 }
 static int narrow_waves(const mile_sampler *s, int S, int N) {
   const int tiles = (N + 15) / 16;

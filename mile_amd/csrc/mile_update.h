@@ -580,8 +580,10 @@ __device__ __forceinline__ bool upd_fast_body(const UpdParams &p, const int e, c
   const float lold_in = (flags & UPD_START) ? 0.0f : p.lold[e];
   const float logp_in = from_slabs ? 0.0f : (p.logp_in ? p.logp_in : p.logp)[e];
   float ll_in = 0.0f;
-  if (from_slabs)
+  if (from_slabs) {
+#pragma unroll 8          // independent loads, several in flight: S is 2 for B2 but up to 64 for narrow nets with few chains
     for (int s = 0; s < p.S; ++s) ll_in += ld1_shared<COH>(p.llpart + (size_t)e * p.S + s);
+  }
 
   constexpr int NR = BIG ? 1 : NK;   // quads of g / noise a thread keeps in registers
   f32x4 cx[BIG ? 1 : NK], cu[NK], cg[NR], ca[NR], cb[NR], csd[SDC ? NK : 1];
@@ -597,6 +599,7 @@ __device__ __forceinline__ bool upd_fast_body(const UpdParams &p, const int e, c
     if (from_slabs) {
       const int so = (int)(o - base);
       g = ld4_slab<AL, COH>(sl, sl_rs, so);
+#pragma unroll 4
       for (int s = 1; s < p.S; ++s) g += ld4_slab<AL, COH>(sl, sl_rs, s * p.dp + so);
     } else {
       g = ld4<AL>(gin + o);
@@ -616,7 +619,11 @@ __device__ __forceinline__ bool upd_fast_body(const UpdParams &p, const int e, c
   if (ntail) {
     const size_t tc = has_tail ? to : base;
     tx = xin[tc]; tu = uin[tc];
-    if (from_slabs) { tg = 0.0f; for (int s = 0; s < p.S; ++s) tg += ld1_shared<COH>(sl + (size_t)s * p.dp + (tc - base)); }
+    if (from_slabs) {
+      tg = 0.0f;
+#pragma unroll 4
+      for (int s = 0; s < p.S; ++s) tg += ld1_shared<COH>(sl + (size_t)s * p.dp + (tc - base));
+    }
     else tg = gin[tc];
     if (SDC) tsd = p.sdc[tc];
     if (explA) ta = p.zA[tc];

@@ -26,6 +26,32 @@ def _next_fast_len(n: int) -> int:
     return best
 
 
+def warm_fft(n_samples: int, device) -> 'threading.Thread | None':
+    """The first torch.fft call of a process spends ~2 s inside rocFFT / hipFFT (library load and kernel cache, measured
+    for every transform length and layout: tools/r03/fft_jit_probe.py) -- as much as 15 000 integrator steps of BASELINE's B2.
+    Phase 3 of the warm-up only needs the FFT after phases 1+2 have run, so that one-off cost is paid on a helper thread and a
+    side stream while the stepping launches go on (PyTorch releases the GIL inside the call).  Same transform length and
+    layout as effective_sample_size will use, so the plan it builds is the one that gets reused."""
+    import threading
+    dev = torch.device(device)
+    if dev.type != 'cuda' or n_samples < 2:
+        return None
+
+    def work():
+        try:
+            with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                m = _next_fast_len(2 * n_samples)
+                x = torch.zeros((1, n_samples, 8), dtype=torch.float32, device=dev)
+                f = torch.fft.rfft(x, n=m, dim=1)
+                torch.fft.irfft(f * f.conj(), n=m, dim=1)
+                torch.cuda.current_stream(dev).synchronize()
+        except Exception:                                  # noqa: BLE001 -- a failed warm-up only means the cost is paid later
+            pass
+    t = threading.Thread(target=work, name='mile-fft-warm', daemon=True)
+    t.start()
+    return t
+
+
 def effective_sample_size(x: torch.Tensor) -> torch.Tensor:
     """x [chains, samples, dims] -> ess [dims]."""
     C, S = x.shape[0], x.shape[1]

@@ -152,6 +152,10 @@ def mclmc_find_L_and_step_size(eng, state: IntegratorState, rng_key, *, tune1_st
                                                   zero_prevention=torch.zeros(E, **f32))
         return state, eps, avg
 
+    fft_warm = None
+    if tune3_steps > 1:                                                   # rocFFT's ~2 s first-call cost, under phases 1+2
+        from mile_amd.diagnostics import warm_fft
+        fft_warm = warm_fft(min(tune3_steps, fft_samples_limit), dev)
     run_steps = run_steps_device if (eng.supports_device_tuner and not force_host_loop) else run_steps_host
     L_cur, sdc_cur = [L], [sdc]
     masks = [1.0] * tune1_steps + [0.0] * tune2_steps
@@ -198,6 +202,8 @@ def mclmc_find_L_and_step_size(eng, state: IntegratorState, rng_key, *, tune1_st
             trace.append(sub)
             done += c
         flat = torch.cat(trace, dim=0).permute(1, 0, 2).contiguous()       # [E, S, P]
+        if fft_warm is not None:
+            fft_warm.join()
         # one ESS per chain and parameter.  With a single chain per call every (chain, parameter) column is
         # independent, so groups of chains go through the estimator as extra columns (bounded workspace)
         # instead of E python-level calls.

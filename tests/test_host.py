@@ -508,6 +508,51 @@ def test_trainer_ranks_share_the_resolved_experiment_dir_world_size_2(tmp_path):
     assert (tmp_path / 'ok0').exists() and (tmp_path / 'ok1').exists()
 
 
+def _empty_rank_worker(rank, ws, port, tmp):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, str(ROOT))
+    import dataclasses
+    import torch.distributed as dist
+    from mile_amd import distributed as md
+    from mile_amd import trainer as T
+    from mile_amd.config import Config
+    cfg = Config.from_file(ROOT / 'experiments' / 'mclmc_airfoil_b1.yaml').replace(saving_dir=str(tmp), logging=False)
+    smp = dataclasses.replace(cfg.training.sampler, n_chains=1)
+    cfg = cfg.replace(training=dataclasses.replace(cfg.training, sampler=smp,
+                                                   warmstart=dataclasses.replace(cfg.training.warmstart, include=False)))
+    seen = []
+
+    def fake_inference_loop(unnorm_log_posterior, config, rng_key, init_params, step_ids, saving_path, saving_path_warmup=None):
+        seen.append(list(step_ids))
+        parts = md.gather_objects((np.full(len(step_ids), 0.5, np.float32), np.full(len(step_ids), 7.0, np.float32)))
+        assert sum(len(p[0]) for p in parts) == 1              # the group's one chain, from whichever rank owns it
+    T.inference_loop = fake_inference_loop
+    t = T.BDETrainer(cfg)
+    t.start_sampling()                                          # used to raise for 1 chain on 2 ranks
+    owners = md.gather_objects(seen)
+    assert sorted(len(o) for o in owners) == [0, 1] and [c for o in owners for g in o for c in g] == [0]
+    # rank 0 failing in setup_dir must fail every rank, not leave them waiting in the broadcast
+    if rank == 0:
+        Config.setup_dir = lambda self: (_ for _ in ()).throw(OSError('disk full'))
+    try:
+        T.BDETrainer(cfg)
+        raised = False
+    except RuntimeError as exc:
+        raised = 'disk full' in str(exc)
+    assert raised
+    torch.save(torch.tensor(1), Path(tmp) / f'ok{rank}')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_rank_without_chains_and_setup_failure_world_size_2(tmp_path):
+    import torch.multiprocessing as mp
+    port = 29300 + os.getpid() % 200
+    mp.spawn(_empty_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / 'ok0').exists() and (tmp_path / 'ok1').exists()
+
+
 def _gather_worker(rank, ws, port, tmp):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
                       MASTER_PORT=str(port))
