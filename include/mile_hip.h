@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MILE_ABI_VERSION 3
+#define MILE_ABI_VERSION 4
 #define MILE_MAX_LAYERS 16
 
 typedef enum mile_status {
@@ -162,6 +162,22 @@ typedef struct mile_tune_args {
   float *out_info;               /* [n_steps, E, 3] or NULL */
 } mile_tune_args;
 
+/* Optimizer of the warm-start stage (src/config/warmstart.py: OptimizerConfig -> optax; src/training/trainer.py:390-538). */
+typedef enum mile_optimizer { MILE_OPT_SGD = 0, MILE_OPT_ADAM = 1, MILE_OPT_ADAMW = 2 } mile_optimizer;
+
+/* One optimizer step of the deep-ensemble members on the current row window (round 3).  Update rules as optax writes them:
+ * m = b1 m + (1 - b1) g, v = b2 v + (1 - b2) g^2, bias-corrected with step count t, update = lr (m^ / (sqrt(v^) + eps)
+ * [+ weight_decay theta for adamw]); sgd: lr g.  g is the gradient of the batch-MEAN negative log-likelihood (no prior:
+ * src/training/trainer.py:729-737). */
+typedef struct mile_optim_args {
+  int32_t kind;                  /* mile_optimizer */
+  float learning_rate, b1, b2, eps, weight_decay;
+  int64_t t;                     /* step count including this step (bias correction) */
+  float *m, *v;                  /* [E, d] moments, caller-owned, updated in place (unused for sgd: may be NULL) */
+  const uint8_t *active;         /* [E] 1 = still training; 0 = early-stopped: parameters AND moments stay frozen.  NULL = all */
+  float *out_nll;                /* [E] batch-mean negative log-likelihood at the parameters BEFORE the update, or NULL */
+} mile_optim_args;
+
 typedef struct mile_sampler mile_sampler;
 
 const char *mile_last_error(void);
@@ -189,6 +205,13 @@ int32_t mile_set_data(mile_sampler *s, const float *X, const void *y, int64_t N,
  * Supported by MILE_GRAD_GENERIC, the MFMA_NARROW, MFMA_W64, MFMA_WIDE and LENET kernels (mile_logpost_grad fails with MILE_ERR_STATE on
  * MFMA_W128_BF16 / GEMM_F32 under a window); the MCLMC path itself is full-batch (n_batches = 1). */
 int32_t mile_set_row_window(mile_sampler *s, int64_t begin, int64_t count);
+
+/* Replaces: one `single_step_regr` / `single_step_class` + `optimizer.update` + `optax.apply_updates` of the warm-start loop
+ * (src/training/trainer.py:706-760, 430-470) for all E members at once: the likelihood gradient of the rows selected by
+ * mile_set_row_window (the minibatch; all rows without a window) from the grad kernel, then ONE fused launch that forms the
+ * batch-mean NLL gradient from the partial-gradient slabs, updates the moments and the parameters in place.  theta [E, d].
+ * Grad kernels with row windows only (see mile_set_row_window). */
+int32_t mile_warmstart_step(mile_sampler *s, float *theta, int32_t E, const mile_optim_args *args, void *stream);
 
 /* Size the internal workspace (partial-gradient slabs etc.) for ensembles of up to E
  * particles.  Allocation happens here, never inside a launch call. */

@@ -7,7 +7,7 @@ from pathlib import Path
 from mile_amd._build import LIB_PATH
 
 MILE_MAX_LAYERS = 16
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 ACTIVATION_IDS = {'relu': 0, 'tanh': 1, 'sigmoid': 2}
 TASK_IDS = {'regr': 0, 'regression': 0, 'classification': 1, 'class': 1}
@@ -75,6 +75,16 @@ class TuneArgsC(C.Structure):
     ]
 
 
+class OptimArgsC(C.Structure):
+    _fields_ = [
+        ('kind', C.c_int32), ('learning_rate', C.c_float), ('b1', C.c_float), ('b2', C.c_float), ('eps', C.c_float),
+        ('weight_decay', C.c_float), ('t', C.c_int64), ('m', C.c_void_p), ('v', C.c_void_p), ('active', C.c_void_p),
+        ('out_nll', C.c_void_p),
+    ]
+
+
+OPTIMIZER_IDS = {'sgd': 0, 'adam': 1, 'adamw': 2}
+
 # name -> (restype, argtypes): every symbol include/mile_hip.h declares
 SIGNATURES = {
     'mile_last_error': (C.c_char_p, []),
@@ -86,6 +96,7 @@ SIGNATURES = {
     'mile_set_data': (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'mile_set_row_window': (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64]),
     'mile_reserve': (C.c_int32, [C.c_void_p, C.c_int32]),
+    'mile_warmstart_step': (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(OptimArgsC), C.c_void_p]),
     'mile_set_grad_kernel': (C.c_int32, [C.c_void_p, C.c_int32]),
     'mile_get_grad_kernel': (C.c_int32, [C.c_void_p]),
     'mile_logpost_grad': (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -177,13 +177,13 @@ static int generic_R(const DevSpec &ds) {
   return R;
 }
 
-// k_grad_narrow: 16-row tiles, workgroups of up to 4 waves.  About two waves per SIMD over the whole grid (8 x CUs waves) and
+// k_grad_narrow: 16-row tiles, workgroups of up to 4 waves.  About four waves per SIMD over the whole grid (16 x CUs waves) and
 // NO MORE row splits than that needs: every split is one more slab the update kernels sum -- with S = 64 splits of a d = 402
 // net the two update launches of a step took 27-31 us each against 6.8 us for the gradient itself (profiles/r03/12_*), the
-// slab / llpart loops being 64 dependent global loads long.  E = 12, N = 1052 (66 tiles): 17 splits of 4 waves; E = 128: 4.
+// slab / llpart loops being 64 dependent global loads long.  E = 12, N = 1052 (66 tiles): 17 splits of 4 waves; E = 128: 8.
 static int narrow_S(const mile_sampler *s, int E) {
   const int tiles = (s->N + 15) / 16;
-  const int waves_per_particle = std::max(1, std::min(tiles, (8 * s->n_cu + std::max(E, 1) - 1) / std::max(E, 1)));
+  const int waves_per_particle = std::max(1, std::min(tiles, (16 * s->n_cu + std::max(E, 1) - 1) / std::max(E, 1)));
   return std::max(1, std::min(64, (waves_per_particle + NRW_MAXW - 1) / NRW_MAXW));
 }
 static int narrow_waves(const mile_sampler *s, int S, int N) {
@@ -1728,6 +1728,27 @@ int32_t mile_logpost_grad(mile_sampler *s, const float *theta, int32_t E, float 
   const int S = choose_S(s, E, resolved_kernel(s));
   k_finalize<<<E, AUX_NT, 0, st>>>(s->ds.d, (s->ds.d + 3) / 4 * 4, S, s->ds.prior, s->ds.prior_loc, s->ds.prior_scale, theta,
                                    s->slabs, s->llpart, grad, logp);
+  HIP_TRY(hipGetLastError());
+  return MILE_OK;
+}
+
+int32_t mile_warmstart_step(mile_sampler *s, float *theta, int32_t E, const mile_optim_args *a, void *stream) {
+  if (!s || !theta || !a || E < 1) return fail(MILE_ERR_INVALID, "mile_warmstart_step: bad argument");
+  if (a->kind < MILE_OPT_SGD || a->kind > MILE_OPT_ADAMW) return fail(MILE_ERR_INVALID, "mile_warmstart_step: unknown optimizer");
+  if (a->kind != MILE_OPT_SGD && (!a->m || !a->v)) return fail(MILE_ERR_INVALID, "mile_warmstart_step: adam / adamw need m and v");
+  if (a->t < 1) return fail(MILE_ERR_INVALID, "mile_warmstart_step: t counts from 1");
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipSetDevice(s->device));
+  const int rc = launch_grad(s, theta, E, st);          // likelihood gradient of the row window -> slabs, llpart
+  if (rc) return rc;
+  OptimParams op{};
+  op.d = s->ds.d; op.S = choose_S(s, E, resolved_kernel(s)); op.dp = (s->ds.d + 3) / 4 * 4; op.kind = a->kind;
+  op.lr = a->learning_rate; op.b1 = a->b1; op.b2 = a->b2; op.eps = a->eps; op.wd = a->weight_decay;
+  op.inv_batch = 1.0f / (float)(s->win_count ? s->win_count : s->N);
+  op.bc1 = (float)(1.0 - std::pow((double)a->b1, (double)a->t));
+  op.bc2 = (float)(1.0 - std::pow((double)a->b2, (double)a->t));
+  op.theta = theta; op.m = a->m; op.v = a->v; op.slabs = s->slabs; op.llpart = s->llpart; op.active = a->active; op.out_nll = a->out_nll;
+  k_optim_step<<<dim3((op.d + 255) / 256, E), 256, 0, st>>>(op);
   HIP_TRY(hipGetLastError());
   return MILE_OK;
 }

@@ -1103,3 +1103,46 @@ static __global__ __launch_bounds__(AUX_NT) void k_tune_post(const TunePostParam
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------
+// Warm-start optimizer step (mile_warmstart_step): g = -(sum_s slab[s]) / B is the gradient of the batch-mean negative
+// log-likelihood (the slabs hold the gradient of the LIKELIHOOD sum; no prior in the warm-start loss, trainer.py:729-737);
+// optax's sgd / adam / adamw update of every member in one launch.  grid (ceil(d / 1024), E).
+struct OptimParams {
+  int32_t d, S, dp, kind;
+  float lr, b1, b2, eps, wd, inv_batch;
+  float bc1, bc2;                 // 1 - b1^t, 1 - b2^t
+  float *theta, *m, *v;
+  const float *slabs, *llpart;
+  const uint8_t *active;
+  float *out_nll;
+};
+static __global__ __launch_bounds__(256) void k_optim_step(const OptimParams p) {
+  const int e = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && p.out_nll) {
+    float ll = 0.0f;
+    for (int s = 0; s < p.S; ++s) ll += p.llpart[(size_t)e * p.S + s];
+    p.out_nll[e] = -ll * p.inv_batch;
+  }
+  if (i >= p.d) return;
+  if (p.active && !p.active[e]) return;                       // early-stopped member: parameters and moments frozen
+  const float *sl = p.slabs + (size_t)e * p.S * p.dp + i;
+  float g = 0.0f;
+#pragma unroll 4
+  for (int s = 0; s < p.S; ++s) g += sl[(size_t)s * p.dp];
+  g = -g * p.inv_batch;
+  const size_t o = (size_t)e * p.d + i;
+  const float th = p.theta[o];
+  float upd;
+  if (p.kind == MILE_OPT_SGD) {
+    upd = p.lr * g;
+  } else {
+    const float m = p.b1 * p.m[o] + (1.0f - p.b1) * g;
+    const float v = p.b2 * p.v[o] + (1.0f - p.b2) * g * g;
+    p.m[o] = m; p.v[o] = v;
+    const float mh = m / p.bc1, vh = v / p.bc2;
+    upd = p.lr * (mh / (sqrtf(vh) + p.eps) + (p.kind == MILE_OPT_ADAMW ? p.wd * th : 0.0f));
+  }
+  p.theta[o] = th - upd;
+}

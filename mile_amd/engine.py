@@ -167,6 +167,38 @@ class Engine:
                                                   self._stream()), self.lib)
         return logp, grad
 
+    def warmstart_step(self, theta: torch.Tensor, optim: dict, active: torch.Tensor | None = None,
+                       want_nll: bool = False) -> torch.Tensor | None:
+        """One optimizer step of all members on the current row window (mile_warmstart_step): likelihood gradient from the
+        grad kernel + ONE fused optimizer launch.  ``theta`` [E, d] and the moments ``optim['m']``, ``optim['v']`` are
+        updated IN PLACE; ``optim`` also carries name, learning_rate, b1, b2, eps, weight_decay and the step count ``t``
+        (incremented here).  ``active`` [E] uint8 / bool: 0 freezes a member (early stopping)."""
+        if theta.dtype != torch.float32 or not theta.is_contiguous() or theta.device != self.device or theta.shape[1] != self.d:
+            raise ValueError(f'theta must be a contiguous fp32 [E, {self.d}] tensor on the engine device')
+        E = theta.shape[0]
+        self.reserve(E)
+        a = _lib.OptimArgsC()
+        a.kind = _lib.OPTIMIZER_IDS[optim['name']]
+        a.learning_rate, a.b1, a.b2 = optim['learning_rate'], optim['b1'], optim['b2']
+        a.eps, a.weight_decay = optim['eps'], optim['weight_decay']
+        optim['t'] += 1
+        a.t = optim['t']
+        if a.kind != 0:
+            for k in ('m', 'v'):
+                t = optim[k]
+                if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != theta.shape or t.device != self.device:
+                    raise ValueError('optimizer moments must match theta')
+            a.m, a.v = optim['m'].data_ptr(), optim['v'].data_ptr()
+        act = None
+        if active is not None:
+            act = active.to(device=self.device, dtype=torch.uint8).contiguous()
+            a.active = act.data_ptr()
+        nll = torch.empty(E, dtype=torch.float32, device=self.device) if want_nll else None
+        a.out_nll = nll.data_ptr() if nll is not None else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mile_warmstart_step(self._h, _ptr(theta), E, C.byref(a), self._stream()), self.lib)
+        return nll
+
     def _state_c(self, st: IntegratorState):
         sc = _lib.StateC()
         sc.n_particles = st.position.shape[0]

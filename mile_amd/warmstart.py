@@ -78,9 +78,17 @@ def train_deep_ensemble(eng, prior, theta0: torch.Tensor, n_train: int, valid_x,
     ``train_x`` / ``train_y`` (the tensors the engine was built on) enable true minibatches; without them, or on a
     grad kernel without row windows, every step sees the whole training set."""
     dev = eng.device
-    theta = theta0.to(dev, torch.float32).clone()
+    theta = theta0.to(dev, torch.float32).clone().contiguous()
     E = theta.shape[0]
+    # Round 3: the step itself runs in the library (mile_warmstart_step: grad kernel + one fused optimizer launch, theta and the
+    # moments updated in place) -- the same update rules as _Optimizer below, which stays as their host-side restatement (CPU
+    # test; MILE_WARMSTART_TORCH=1 runs it instead, on `grad(log posterior) - grad(log prior)`, whose rounding residue Adam
+    # amplifies on units with an exactly-zero likelihood gradient -- a debugging path, not a second product path).  ~30 elementwise torch launches per step were 1.1 ms of a 1.2 ms step.
+    import os
+    fused = os.environ.get('MILE_WARMSTART_TORCH') is None
     opt = _Optimizer(optimizer, optimizer_parameters or {}, theta)
+    ostate = {'name': opt.name, 'learning_rate': opt.lr, 'b1': opt.b1, 'b2': opt.b2, 'eps': opt.eps, 'weight_decay': opt.wd,
+              't': 0, 'm': opt.m, 'v': opt.v}
     WINDOWED = ('generic', 'mfma_narrow_f32', 'mfma_w64', 'mfma_w64_bf16x3', 'mfma_wide_bf16x3', 'mfma_wide_bf16', 'lenet_f32', 'lenet_bf16')
     want_minibatch = bool(batch_size) and batch_size < n_train and train_x is not None and train_y is not None
     sampler_kernel = eng.grad_kernel
@@ -110,21 +118,29 @@ def train_deep_ensemble(eng, prior, theta0: torch.Tensor, n_train: int, valid_x,
             if minibatch:
                 perm = torch.randperm(n_train, generator=gen)                # loader.shuffle() between epochs
                 eng.set_data(tx[perm], ty[perm])
+                active = ~stopped
                 for b in range(n_batches):
                     eng.set_row_window(b * batch_size, batch_size)
+                    if fused:
+                        train_nll = eng.warmstart_step(theta, ostate, active, want_nll=(b == n_batches - 1))
+                        continue
                     logp, g = eng.logpost_grad(theta)
                     lp_prior, g_prior = prior_value_and_grad(prior, theta)
                     grad_nll = -(g - g_prior) / batch_size                   # gradient of the batch-mean negative log-likelihood
                     train_nll = -(logp - lp_prior) / batch_size
-                    theta = opt.step(theta, grad_nll, ~stopped)
+                    theta = opt.step(theta, grad_nll, active)
                 eng.set_row_window(0, 0)
             else:
-                for _ in range(steps_per_epoch):
+                active = ~stopped
+                for k in range(steps_per_epoch):
+                    if fused:
+                        train_nll = eng.warmstart_step(theta, ostate, active, want_nll=(k == steps_per_epoch - 1))
+                        continue
                     logp, g = eng.logpost_grad(theta)
                     lp_prior, g_prior = prior_value_and_grad(prior, theta)
                     grad_nll = -(g - g_prior) / n_train                      # gradient of the mean negative log-likelihood
                     train_nll = -(logp - lp_prior) / n_train
-                    theta = opt.step(theta, grad_nll, ~stopped)
+                    theta = opt.step(theta, grad_nll, active)
             if has_valid:
                 v = -eng.pointwise_loglik(theta, valid_x, valid_y).mean(dim=-1)          # [E]
                 hist_valid = torch.cat([hist_valid, v[:, None]], dim=1)
