@@ -88,13 +88,16 @@ static bool w64_supported(const mile_model_spec &sp) {
 }
 
 // the split-bf16 variant replaces the hidden->hidden products, so it needs at least one
-// k_grad_narrow: 1-3 hidden layers of width <= 32, F <= 64, <= 16 outputs (regression: exactly mu, log sigma), any activation
+// k_grad_narrow: 1-3 hidden layers of width <= 32 and F <= 64, or 4-10 hidden layers of width <= 16 and F <= 16 (the depth
+// ablations of the reference: experiments/**: [16]*4 .. [16]*9 + [2], [8]*6 + [2]); <= 16 outputs (regression: exactly mu,
+// log sigma), any activation
 static bool narrow_supported(const mile_model_spec &sp) {
   if (sp.model != MILE_MODEL_FCN || !sp.use_bias) return false;
   const int nh = sp.n_layers - 1;
-  if (nh < 1 || nh > 3 || sp.in_features > 64) return false;
+  if (nh < 1 || nh > 10 || sp.in_features > 64) return false;
   for (int l = 0; l < nh; ++l)
-    if (sp.widths[l] < 1 || sp.widths[l] > 32) return false;
+    if (sp.widths[l] < 1 || sp.widths[l] > (nh > 3 ? 16 : 32)) return false;
+  if (nh > 3 && sp.in_features > 16) return false;
   const int K = sp.widths[nh];
   if (K < 1 || K > 16) return false;
   if (sp.task == MILE_TASK_REGRESSION && K != 2) return false;
@@ -483,7 +486,7 @@ int32_t mile_set_grad_kernel(mile_sampler *s, int32_t which) {
   if (!s) return fail(MILE_ERR_INVALID, "null handle");
   if (which < MILE_GRAD_AUTO || which > MILE_GRAD_MFMA_NARROW_F32) return fail(MILE_ERR_INVALID, "unknown grad kernel");
   if (which == MILE_GRAD_MFMA_NARROW_F32 && !narrow_supported(s->spec))
-    return fail(MILE_ERR_INVALID, "MFMA_NARROW_F32 needs an FCN with 1-3 hidden layers of width <= 32, F <= 64 and <= 16 outputs");
+    return fail(MILE_ERR_INVALID, "MFMA_NARROW_F32 needs an FCN with 1-3 hidden layers of width <= 32 and F <= 64 (or 4-10 of width <= 16 and F <= 16) and <= 16 outputs");
   if ((which == MILE_GRAD_MFMA_WIDE_BF16X3 || which == MILE_GRAD_MFMA_WIDE_BF16) && s->spec.model != MILE_MODEL_FCN)
     return fail(MILE_ERR_INVALID, "MFMA_WIDE_* are FCN kernels");
   if ((s->spec.model == MILE_MODEL_LENET) != (which == MILE_GRAD_LENET_F32 || which == MILE_GRAD_LENET_BF16) && which != MILE_GRAD_AUTO)
@@ -665,6 +668,7 @@ static hipError_t launch_narrow(const mile_sampler *s, const GradParams &gp, int
   MILE_NRW(1, 1, 1) MILE_NRW(1, 2, 1) MILE_NRW(1, 1, 4) MILE_NRW(1, 2, 4)
   MILE_NRW(2, 1, 1) MILE_NRW(2, 2, 1) MILE_NRW(2, 1, 4) MILE_NRW(2, 2, 4)
   MILE_NRW(3, 1, 1) MILE_NRW(3, 2, 1) MILE_NRW(3, 1, 4) MILE_NRW(3, 2, 4)
+  MILE_NRW(4, 1, 1) MILE_NRW(5, 1, 1) MILE_NRW(6, 1, 1) MILE_NRW(7, 1, 1) MILE_NRW(8, 1, 1) MILE_NRW(9, 1, 1) MILE_NRW(10, 1, 1)
 #undef MILE_NRW
   return hipErrorInvalidValue;
 }
@@ -1670,7 +1674,7 @@ int32_t mile_grad_launch_info(const mile_sampler *s, int32_t E, int32_t *grid_x,
   } else if (kernel == MILE_GRAD_MFMA_NARROW_F32) {
     nm = "k_grad_narrow";
     if (block) *block = 64 * narrow_waves(s, S, s->N);
-    lds = NarrowLayout<3, 2, 4>::BYTES;   // upper bound over the instantiations
+    lds = std::max(NarrowLayout<3, 2, 4>::BYTES, NarrowLayout<10, 1, 1>::BYTES);   // upper bound over the instantiations
   } else if (kernel == MILE_GRAD_LENET_BF16) {
     nm = "k_conv5m_fwd/dx/dw (implicit-GEMM bf16 MFMA) + k_mm3 (Dense, fp32-faithful three-term products)";
     lds = (int)cm_lds_dw(CM_IN8, s->lg.hp1, s->lg.wp1, 0);

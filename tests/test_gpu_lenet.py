@@ -163,7 +163,7 @@ def test_full_size_properties_config5_lenet(LN):
     """BASELINE config 5 at its full ensemble (CIFAR-shaped LeNet, E = 256 particles; 1 000 images keep the test in seconds) on the
     MFMA convolution path: agreement with the fp32 direct-convolution path at the bf16 recipe's cost, additivity over images,
     permutation equivariance over particles (bit-exact), determinism and unit momentum through MCLMC steps (d = 83 126 takes the
-    two-pass update)."""
+    segmented update `k_update_seg`: segments of 8192 elements on all CUs)."""
     ospec = LN.LeNetSpec(3, 32, 32, 10)
     N, E = 1000, 256
     prob = LN.synthetic_problem(ospec, N, E, seed=0)

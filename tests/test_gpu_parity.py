@@ -46,6 +46,11 @@ CASES = [
     (5, (16, 16, 2), 'relu', 'regr', 'Normal', 2, 1, ('generic', 'mfma_narrow_f32')),
     (5, (16, 16, 2), 'relu', 'regr', 'Normal', 17, 300, ('generic', 'mfma_narrow_f32')),
     (16, (32, 16, 3), 'relu', 'classification', 'Normal', 4099, 2, ('generic', 'mfma_narrow_f32')),
+    # the depth ablations among the reference's YAMLs: [16]*4 + [2], [8]*6 + [2], [16]*9 + [2]
+    (5, (16, 16, 16, 16, 2), 'relu', 'regr', 'Normal', 400, 3, ('generic', 'mfma_narrow_f32', 'auto')),
+    (8, (8, 8, 8, 8, 8, 8, 2), 'relu', 'regr', 'Normal', 203, 2, ('generic', 'mfma_narrow_f32')),
+    (13, (16,) * 9 + (2,), 'tanh', 'regr', 'Normal', 150, 2, ('generic', 'mfma_narrow_f32')),
+    (6, (12,) * 10 + (4,), 'sigmoid', 'classification', 'Normal', 90, 2, ('generic', 'mfma_narrow_f32')),
     (54, (40, 40, 7), 'relu', 'classification', 'Laplace', 130, 3, ('generic', 'gemm_f32', 'mfma_wide_bf16x3')),
     # wide nets: the layer-wise paths -- hand-written MFMA GEMMs (what AUTO picks there) and rocBLAS (the cross-check) --
     # B3- and B4-shaped, and shapes that leave ragged 128 x 128 x 64 tiles in every dimension
@@ -80,7 +85,7 @@ def test_logpost_grad_matches_oracle(oracle, F, hs, act, task, prior, N, E, kern
         near = np.zeros(N, dtype=bool)
         for z in zs[:-1]:
             near |= (np.abs(z) < 3e-7 * np.abs(z).max()).any(axis=(0, 2))
-        assert near.sum() <= 17, near.sum()            # what the worst case in CASES needs (measured: (F=8, N=1057))
+        assert near.sum() <= 17, near.sum()            # what the worst case in CASES needs (measured: 5, (F=8, N=1057))
         if (F, N) == (8, 1057):
             assert near.any()                        # the case this mask exists for
         if near.any() and near.sum() < N:
