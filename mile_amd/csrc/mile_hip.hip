@@ -525,9 +525,15 @@ static void launch_update_al(const UpdParams &u, int E, int nk, hipStream_t st) 
   if constexpr (!SDC) {                                                                          \
     if (kind == UPD_KIND_MID) { k_update_fast<NK_, AL, SDC, UPD_KIND_MID><<<E, nt, 0, st>>>(u); break; } \
     if (kind == UPD_KIND_REC) { k_update_fast<NK_, AL, SDC, UPD_KIND_REC><<<E, nt, 0, st>>>(u); break; } \
-    if (kind == UPD_KIND_TUNE) { k_update_fast<NK_, AL, SDC, UPD_KIND_TUNE><<<E, nt, 0, st>>>(u); break; } \
+    if (kind == UPD_KIND_TUNE) {                                                                 \
+      if (nt <= 768) k_update_fast<NK_, AL, SDC, UPD_KIND_TUNE, 768><<<E, nt, 0, st>>>(u);       \
+      else k_update_fast<NK_, AL, SDC, UPD_KIND_TUNE><<<E, nt, 0, st>>>(u);                      \
+      break;                                                                                     \
+    }                                                                                            \
   }                                                                                              \
-  k_update_fast<NK_, AL, SDC><<<E, nt, 0, st>>>(u); break;
+  if (nt <= 768) k_update_fast<NK_, AL, SDC, -1, 768><<<E, nt, 0, st>>>(u);                      \
+  else k_update_fast<NK_, AL, SDC><<<E, nt, 0, st>>>(u);                                         \
+  break;
   switch (nk) {
     case 1: MILE_UPD_CASE(1)
     case 2: MILE_UPD_CASE(2)

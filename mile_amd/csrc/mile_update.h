@@ -919,8 +919,11 @@ __device__ __forceinline__ void upd_tune_restart(const UpdParams &p, const int e
   upd_fast_body<NK, AL, SDC, false, -1>(q, e, tid, nt, red, bc);
 }
 
-template <int NK, int AL, bool SDC, int CF = -1>
-static __global__ __launch_bounds__(UPD_NT) void k_update_fast(const UpdParams p) {
+// MAXT: the launch bound.  A launch never uses more threads than the quads need (d = 8834: 768), and a kernel promised
+// <= 768 threads may use 170 registers instead of 128: the warm-up record kind (two coefficient sets, the restart path) spilled
+// 19 VGPRs / 45 SGPRs under the 1024-thread bound.
+template <int NK, int AL, bool SDC, int CF = -1, int MAXT = UPD_NT>
+static __global__ __launch_bounds__(MAXT) void k_update_fast(const UpdParams p) {
   __shared__ float red[UPD_NW][UPD_NSUM + 1];
   __shared__ float bc[16];
   // launched with the fewest waves that still give NK quads per thread (nt = blockDim.x <= UPD_NT, a multiple of 64): the

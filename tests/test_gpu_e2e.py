@@ -779,7 +779,11 @@ def test_fused_warmstart_step_matches_the_optax_rules(oracle, monkeypatch, F, hs
     eng.set_row_window(0, 0)
     torch.cuda.synchronize()
     assert torch.equal(th_a[2].cpu(), torch.from_numpy(prob['theta0'][2]))              # frozen member untouched
-    assert _rel(th_a.cpu(), th_b) < 2e-5
+    # sgd: fp32 rounding of the gradient only.  adam / adamw divide by sqrt(v) + 1e-8: on entries whose likelihood gradient is
+    # itself rounding-sized (|g| <~ 1e-7 max |g|: nearly-dead units) m / sqrt(v) is O(1) whatever the noise is, so fp32 and fp64
+    # gradients give updates that differ by a good part of lr there -- up to 1.7e-4 of max |theta| after six steps (measured;
+    # fp32 JAX against fp64 JAX would show the same).  The moments themselves agree to 1e-4.
+    assert _rel(th_a.cpu(), th_b) < (2e-5 if opt == 'sgd' else 5e-4)
     if opt != 'sgd':
         assert _rel(ost['m'].cpu(), ref.m) < 1e-4 and _rel(ost['v'].cpu(), ref.v) < 1e-4
         assert ost['m'][2].abs().max().item() == 0.0 and ost['t'] == 6

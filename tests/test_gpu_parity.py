@@ -102,6 +102,46 @@ def test_logpost_grad_matches_oracle(oracle, F, hs, act, task, prior, N, E, kern
         assert _relerr(g.cpu().numpy(), g_ref) < 2e-5, k
 
 
+def test_narrow_kernel_on_random_specs(oracle):
+    """k_grad_narrow over 30 random FCN specs inside its support (1-3 hidden layers of width 1..32 with F <= 64, or 4-10 of
+    width 1..16 with F <= 16; 1..16 classes or the (mu, log sigma) head; relu / tanh / sigmoid; N from below one tile to a
+    few hundred rows; 1..7 particles) against the fp64 oracle at the tolerance of the parity table, and against the generic
+    kernel; AUTO must pick it for every one of them."""
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for it in range(30):
+        deep = it % 3 == 2
+        nh = int(rng.integers(4, 11)) if deep else int(rng.integers(1, 4))
+        wmax = 16 if deep else 32
+        F = int(rng.integers(1, 17 if deep else 65))
+        hidden = tuple(int(rng.integers(1, wmax + 1)) for _ in range(nh))
+        task = 'regr' if rng.random() < 0.5 else 'classification'
+        K = 2 if task == 'regr' else int(rng.integers(2, 17))
+        act = ('relu', 'tanh', 'sigmoid')[int(rng.integers(0, 3))]
+        N, E = int(rng.integers(1, 400)), int(rng.integers(1, 8))
+        ospec = oracle.ModelSpec(F, hidden + (K,), activation=act, task=task)
+        prob = oracle.synthetic_problem(ospec, N, E, seed=100 + it)
+        if act == 'relu':
+            _, zs, _ = oracle.mlp_forward(ospec, prob['theta0'].astype(np.float64), prob['X'], keep=True)
+            near = np.zeros(N, dtype=bool)
+            for z in zs[:-1]:
+                near |= (np.abs(z) < 3e-7 * max(np.abs(z).max(), 1e-30)).any(axis=(0, 2))
+            if near.any() and near.sum() < N:
+                prob = dict(prob, X=np.ascontiguousarray(prob['X'][~near]), y=np.ascontiguousarray(prob['y'][~near]))
+        lp_ref, g_ref = oracle.logpost_and_grad(ospec, prob['theta0'].astype(np.float64), prob['X'], prob['y'])
+        eng = _engine(oracle, ospec, prob, 'auto')
+        assert eng.grad_kernel == 'mfma_narrow_f32', (F, hidden, K)
+        lp, g = eng.logpost_grad(torch.from_numpy(prob['theta0']))
+        lpg, gg = _engine(oracle, ospec, prob, 'generic').logpost_grad(torch.from_numpy(prob['theta0']))
+        torch.cuda.synchronize()
+        tag = (it, F, hidden, K, act, task, N, E)
+        assert _relerr(lp.cpu().numpy(), lp_ref) < 2e-5, tag
+        assert _relerr(g.cpu().numpy(), g_ref) < 2e-5, tag
+        assert _relerr(g.cpu().numpy(), gg.cpu().numpy()) < 2e-5, tag
+        worst = max(worst, _relerr(g.cpu().numpy(), g_ref))
+    print('narrow kernel, 30 random specs: worst gradient error vs fp64 %.2e of max |g|' % worst)
+
+
 def test_wide_path_is_not_poisoned_by_a_previous_non_finite_call(oracle):
     """launch_grad_wide shares two dZ buffers between layers of different padded widths (hidden widths that are
     not multiples of 8 and differ: 100 / 50 / 20 -> leading dimensions 104 / 56 / 24).  A layer's padding columns are not

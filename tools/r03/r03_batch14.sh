@@ -15,3 +15,4 @@ print({k: d[k] for k in ('value', 'ms_per_step')}, d['roofline']['frac'], d['roo
 for k, v in d.get('secondary', {}).items():
     print(k, {q: v.get(q) for q in ('value', 'ms_per_step', 'error')}, (v.get('roofline') or {}).get('frac'), (v.get('cpu_baseline') or {}).get('value'))
 PY
+bash tools/r03/pmc_whole_gradient.sh r3o/b5_traffic k_conv5m_fwd2x --workload B5 --steps 4 --warmup 1 > $O/b5_traffic.txt 2>&1; tail -n 25 $O/b5_traffic.txt
