@@ -2005,6 +2005,7 @@ int32_t mile_tune(mile_sampler *s, mile_state *state, const mile_tune_args *a, v
         u.x_in = nxt.x; u.u_in = nxt.u;          // the step ran in nxt; its accepted state stays there ...
         u.x_acc = nxt.x; u.u_rec = nxt.u;
         u.x = cur.x; u.u = cur.u;                // ... and the next step's working state goes to the other buffer
+        u.force_restart = getenv("MILE_TUNE_FORCE_RESTART") != nullptr;
       }
       const int rc = grad_then_update(s, nxt.x, E, u, fused, st);
       if (rc) return rc;

@@ -64,6 +64,7 @@ struct UpdParams {
   // next step's working position / momentum go to x / u (the other buffer, which bk_* names: the state before this step).
   float *u_rec;                  // [E, d] momentum at the record point (nan_to_num'd), or NULL: plain record launch
   float *x_acc;                  // [E, d] == x_in, writable: a rejected chain gets bk_x back here
+  int32_t force_restart;         // test hook (MILE_TUNE_FORCE_RESTART): every chain takes the restart path of the merged launch
 };
 
 // B / O chain on the coefficients of {u, e, zA, zB}; norms and projections come from the
@@ -781,7 +782,8 @@ __device__ __forceinline__ bool upd_fast_body(const UpdParams &p, const int e, c
     eps_next = en;                                            // params_new.step_size: what the next kernel step uses
     // the next step's ops can be formed from THIS launch's Gram matrix only if the accepted momentum / gradient are the
     // vectors it was built from, i.e. nan_to_num changed nothing: all finite
-    t_simple = t_ok && isfinite(S[2]) && isfinite(S[0]) && isfinite(r0) && isfinite(r1) && isfinite(r2) && isfinite(r3);
+    t_simple = t_ok && isfinite(S[2]) && isfinite(S[0]) && isfinite(r0) && isfinite(r1) && isfinite(r2) && isfinite(r3) &&
+               !p.force_restart;
     if (merged) lold = logp_now;
     if (tid == 0) {
       p.t_eps[e] = en;

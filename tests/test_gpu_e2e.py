@@ -518,14 +518,20 @@ def test_device_tuner_matches_host_loop(oracle):
     assert _rel(outp[False][1].step_size.cpu(), outp[True][1].step_size.cpu()) < 5e-2
 
 
-@pytest.mark.parametrize('F,hs,sdc', [(5, (64, 64, 64, 2), False), (5, (16, 16, 2), False), (7, (9, 6, 2), True)])
-def test_merged_warmup_launch_matches_the_five_launch_form(oracle, monkeypatch, F, hs, sdc):
+@pytest.mark.parametrize('F,hs,sdc,force_restart', [(5, (64, 64, 64, 2), False, False), (5, (16, 16, 2), False, False),
+                                                    (7, (9, 6, 2), True, False), (5, (64, 64, 64, 2), False, True),
+                                                    (7, (9, 6, 2), True, True)])
+def test_merged_warmup_launch_matches_the_five_launch_form(oracle, monkeypatch, F, hs, sdc, force_restart):
     """Round 3: a warm-up step is four launches like a sampling step -- the record-point launch (B, O, record, tuner) also
     runs the NEXT step's O, B, A with the step size it has just computed, and writes them into the other ping-pong buffer.
     Against the five-launch form of rounds 1-2 (MILE_TUNE_NO_MERGE=1; also what a 1-step call does), same Philox streams,
     14 steps across the tune1 / tune2 boundary: same state, step sizes, adaptive state and streaming averages to fp32
     summation order.  Chain 1 starts at 1e18 (NaN gradient -> every step rejected): the merged launch then restarts the
-    next step from the restored state inside the same kernel (upd_tune_restart) -- bit-identical bookkeeping expected."""
+    next step from the restored state inside the same kernel (upd_tune_restart) -- bit-identical bookkeeping expected.
+    `force_restart`: the test hook MILE_TUNE_FORCE_RESTART sends EVERY chain through that restart path (what an accepted state
+    that nan_to_num changed would take), which must give the same run."""
+    if force_restart:
+        monkeypatch.setenv('MILE_TUNE_FORCE_RESTART', '1')
     ospec = oracle.ModelSpec(F, hs)
     E, d = 4, ospec.n_params
     prob = oracle.synthetic_problem(ospec, 120, E, seed=9)
