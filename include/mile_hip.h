@@ -73,7 +73,7 @@ typedef enum mile_grad_kernel {
                                      three-term bf16 products, bias / activation / activation-derivative fused into their
                                      epilogues; what AUTO picks for wide nets (hidden width >= 96: B4's 4 x 256 softmax net) */
   MILE_GRAD_MFMA_WIDE_BF16 = 8,   /* the same kernels with bf16-ROUNDED operands (one product instead of six); explicit only */
-  MILE_GRAD_MFMA_NARROW_F32 = 10, /* FCNs with 1-3 hidden layers of width <= 32, F <= 64 inputs (or 4-10 hidden layers of width <= 16,
+  MILE_GRAD_MFMA_NARROW_F32 = 10, /* FCNs with 1-3 hidden layers of width <= 64, F <= 64 inputs (or 4-10 hidden layers of width <= 16,
                                      F <= 16: the reference's depth ablations), <= 16 outputs, any activation,
                                      either head: fused forward + backward on v_mfma_f32_16x16x4_f32 (fp32 operands -- exact fp32
                                      products, fp32 accumulation); what AUTO picks for the reference's own 16- / 32-wide nets

@@ -4,7 +4,8 @@
 // the README example [16,16,16,2], experiments/datasize_ablation/protein_mclmc.yaml [16,16,16,2] (ReLU regression) and
 // experiments/tabluar_classif/covertype.yaml [32,7] (sigmoid, 7-class softmax head).  Until round 3 they all took
 // k_grad_generic (VALU, one FMA chain per output element, weights through L1).  This kernel covers 1-3 hidden layers of width
-// <= 32, F <= 64 inputs, <= 16 outputs, ReLU / tanh / sigmoid (src/config/models/base.py:25-39), both heads
+// <= 64 (<= 32: weights in registers; 33..64: weights in LDS, template flag WL) or 4-10 hidden layers of width <= 16 (the
+// reference's depth ablations), F <= 64 inputs, <= 16 outputs, ReLU / tanh / sigmoid (src/config/models/base.py:25-39), both heads
 // (src/training/probabilistic.py:92-109) in one fused forward + backward pass per 16-row tile, every Dense product
 // (src/flax_building_blocks/basic.py:42-61) on v_mfma_f32_16x16x4_f32: fp32 operands, a k-ordered fp32 fmaf chain per output --
 // fp32 arithmetic proper, no bf16 split needed (at these widths the matrix pipe is nowhere near the bound; the kernel is
@@ -32,13 +33,24 @@
 #define NRW_MAXW 4              // waves per workgroup (upper bound)
 #define NRW_TS 20               // row stride (floats) of the per-wave transposition image
 
-template <int NH, int TH, int TF>
+// WL = true (hidden widths 33..64, TH = 3 or 4): the weights do not fit the register file next to the accumulators any more and
+// live in LDS instead, as padded fp32 images in BOTH operand orientations (row stride = 16 T + 4 floats: the four lane groups of
+// an A-operand read then fall on four different quarters of the banks, conflict-free): forward images [in][out], dH images
+// [out][in].  The cross-wave reduction buffer aliases them after the tile loop.
+template <int NH, int TH, int TF, bool WL = false>
 struct NarrowLayout {
   static constexpr int TRANS = NRW_MAXW * 16 * NRW_TS;                         // per-wave 16 x 20 images
   // cross-wave reduction image: one wave's accumulators, 64 lanes x NACC floats
   static constexpr int NACC = 4 * (TF * TH + (NH - 1) * TH * TH + TH) + (NH * TH + 1) + 1;
   static constexpr int RED = 64 * NACC;
-  static constexpr int FLOATS = TRANS + RED;
+  static constexpr int HP = 16 * TH, SH = HP + 4, SL = 20;                     // padded hidden width and the image row strides
+  static constexpr int W0F = 0;                                                // [16 TF][SH]
+  static constexpr int WHF = W0F + 16 * TF * SH;                               // (NH - 1) x [HP][SH]
+  static constexpr int WHB = WHF + (NH - 1) * HP * SH;                         // (NH - 1) x [HP][SH], transposed
+  static constexpr int WLF = WHB + (NH - 1) * HP * SH;                         // [HP][SL]
+  static constexpr int WLB = WLF + HP * SL;                                    // [16][SH], transposed
+  static constexpr int WTOT = WLB + 16 * SH;
+  static constexpr int FLOATS = TRANS + (WL ? (WTOT > RED ? WTOT : RED) : RED);
   static constexpr int BYTES = FLOATS * 4;
 };
 
@@ -59,10 +71,10 @@ __device__ __forceinline__ f32x4 nrw_transpose(float *img, int g, int c, const f
 __device__ __forceinline__ float nrw_xor16(float v) { return __shfl_xor(v, 16, 64); }
 __device__ __forceinline__ float nrw_xor32(float v) { return __shfl_xor(v, 32, 64); }
 
-template <int NH, int TH, int TF>
+template <int NH, int TH, int TF, bool WL = false>
 static __global__ __launch_bounds__(64 * NRW_MAXW) void k_grad_narrow(const GradParams p) {
   extern __shared__ __attribute__((aligned(16))) float nrw_lds[];
-  using LY = NarrowLayout<NH, TH, TF>;
+  using LY = NarrowLayout<NH, TH, TF, WL>;
   const DevSpec &sp = p.spec;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int g = lane >> 4, c = lane & 15;
@@ -75,13 +87,72 @@ static __global__ __launch_bounds__(64 * NRW_MAXW) void k_grad_narrow(const Grad
   // ---- weights -> registers, both operand arrangements (zero beyond the real widths) ---------------------------------
   // forward (A of Z^T = W^T H^T):  wf[ti][t][j] = W[in 16 ti + 4 g + j][out 16 t + c]
   // dH      (A of dH^T = W dZ^T):  wb[ti][t][j] = W[in 16 ti + c][out 16 t + 4 g + j]
-  float w0f[TF][TH][4];
-  float whf[NH > 1 ? NH - 1 : 1][TH][TH][4], whb[NH > 1 ? NH - 1 : 1][TH][TH][4];
-  float wlf[TH][4], wlb[TH][4];
+  constexpr int WR = WL ? 1 : TH, WRF = WL ? 1 : TF;             // (register weight arrays collapse in the LDS form)
+  float w0f[WRF][WR][4];
+  float whf[NH > 1 ? NH - 1 : 1][WR][WR][4], whb[NH > 1 ? NH - 1 : 1][WR][WR][4];
+  float wlf[WR][4], wlb[WR][4];
   float b0[TH][4], bh[NH > 1 ? NH - 1 : 1][TH][4], bl[4];        // biases in L2: reg j <-> feature 4 g + j
+  float *wimg = nrw_lds + LY::TRANS;                              // WL: the weight images
+  if constexpr (WL) {
+    const int nt = blockDim.x;
+    {  // first layer, forward image [in][out]
+      const int o0 = sp.widths[0];
+      const float *W = th + sp.w_off[0];
+      for (int i = tid; i < 16 * TF * LY::SH; i += nt) {
+        const int in = i / LY::SH, out = i - in * LY::SH;
+        wimg[LY::W0F + i] = (in < F && out < o0) ? W[in * o0 + out] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int l = 1; l < NH; ++l) {
+      const int wi = sp.widths[l - 1], wo = sp.widths[l];
+      const float *W = th + sp.w_off[l];
+      float *Wf = wimg + LY::WHF + (l - 1) * LY::HP * LY::SH, *Wb = wimg + LY::WHB + (l - 1) * LY::HP * LY::SH;
+      for (int i = tid; i < LY::HP * LY::SH; i += nt) {
+        const int r = i / LY::SH, q = i - r * LY::SH;
+        Wf[i] = (r < wi && q < wo) ? W[r * wo + q] : 0.0f;          // [in r][out q]
+        Wb[i] = (q < wi && r < wo) ? W[q * wo + r] : 0.0f;          // [out r][in q]
+      }
+    }
+    {
+      const int wi = sp.widths[NH - 1];
+      const float *W = th + sp.w_off[NH];
+      for (int i = tid; i < LY::HP * LY::SL; i += nt) {
+        const int in = i / LY::SL, k = i - in * LY::SL;
+        wimg[LY::WLF + i] = (in < wi && k < K) ? W[in * K + k] : 0.0f;
+      }
+      for (int i = tid; i < 16 * LY::SH; i += nt) {
+        const int k = i / LY::SH, in = i - k * LY::SH;
+        wimg[LY::WLB + i] = (in < wi && k < K) ? W[in * K + k] : 0.0f;
+      }
+    }
+    __syncthreads();
+  }
+  // A operands of the five kinds of product: from registers, or (WL) one ds_read_b32 per MFMA from the images
+  auto a_f0 = [&](int ti, int t, int j) -> float {
+    if constexpr (WL) return wimg[LY::W0F + (16 * ti + 4 * g + j) * LY::SH + 16 * t + c];
+    else return w0f[ti][t][j];
+  };
+  auto a_fh = [&](int l, int ti, int t, int j) -> float {
+    if constexpr (WL) return wimg[LY::WHF + (l - 1) * LY::HP * LY::SH + (16 * ti + 4 * g + j) * LY::SH + 16 * t + c];
+    else return whf[l - 1][ti][t][j];
+  };
+  auto a_bh = [&](int l, int ti, int t, int j) -> float {
+    if constexpr (WL) return wimg[LY::WHB + (l - 1) * LY::HP * LY::SH + (16 * t + 4 * g + j) * LY::SH + 16 * ti + c];
+    else return whb[l - 1][ti][t][j];
+  };
+  auto a_fl = [&](int ti, int j) -> float {
+    if constexpr (WL) return wimg[LY::WLF + (16 * ti + 4 * g + j) * LY::SL + c];
+    else return wlf[ti][j];
+  };
+  auto a_bl = [&](int ti, int j) -> float {
+    if constexpr (WL) return wimg[LY::WLB + (4 * g + j) * LY::SH + 16 * ti + c];
+    else return wlb[ti][j];
+  };
   {
     const int o0 = sp.widths[0];
     const float *W = th + sp.w_off[0], *B = th + sp.b_off[0];
+    if constexpr (!WL) {
 #pragma unroll
     for (int ti = 0; ti < TF; ++ti)
 #pragma unroll
@@ -91,6 +162,7 @@ static __global__ __launch_bounds__(64 * NRW_MAXW) void k_grad_narrow(const Grad
           const int in = 16 * ti + 4 * g + j, out = 16 * t + c;
           w0f[ti][t][j] = (in < F && out < o0) ? W[in * o0 + out] : 0.0f;
         }
+    }
 #pragma unroll
     for (int t = 0; t < TH; ++t)
 #pragma unroll
@@ -100,6 +172,7 @@ static __global__ __launch_bounds__(64 * NRW_MAXW) void k_grad_narrow(const Grad
   for (int l = 1; l < NH; ++l) {
     const int wi = sp.widths[l - 1], wo = sp.widths[l];
     const float *W = th + sp.w_off[l], *B = th + sp.b_off[l];
+    if constexpr (!WL) {
 #pragma unroll
     for (int ti = 0; ti < TH; ++ti)
 #pragma unroll
@@ -111,6 +184,8 @@ static __global__ __launch_bounds__(64 * NRW_MAXW) void k_grad_narrow(const Grad
           const int inb = 16 * ti + c, outb = 16 * t + 4 * g + j;
           whb[l - 1][ti][t][j] = (inb < wi && outb < wo) ? W[inb * wo + outb] : 0.0f;
         }
+    }
+    (void)wi;
 #pragma unroll
     for (int t = 0; t < TH; ++t)
 #pragma unroll
@@ -119,6 +194,7 @@ static __global__ __launch_bounds__(64 * NRW_MAXW) void k_grad_narrow(const Grad
   {
     const int wi = sp.widths[NH - 1];
     const float *W = th + sp.w_off[NH], *B = th + sp.b_off[NH];
+    if constexpr (!WL) {
 #pragma unroll
     for (int ti = 0; ti < TH; ++ti)
 #pragma unroll
@@ -128,6 +204,8 @@ static __global__ __launch_bounds__(64 * NRW_MAXW) void k_grad_narrow(const Grad
         const int inb = 16 * ti + c, outb = 4 * g + j;
         wlb[ti][j] = (inb < wi && outb < K) ? W[inb * K + outb] : 0.0f;
       }
+    }
+    (void)wi; (void)W;
 #pragma unroll
     for (int j = 0; j < 4; ++j) bl[j] = (4 * g + j < K) ? B[4 * g + j] : 0.0f;
   }
@@ -178,7 +256,7 @@ static __global__ __launch_bounds__(64 * NRW_MAXW) void k_grad_narrow(const Grad
 #pragma unroll
       for (int ti = 0; ti < TF; ++ti)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) z = nrw_mfma(w0f[ti][t][j], x2[ti][j], z);
+        for (int j = 0; j < 4; ++j) z = nrw_mfma(a_f0(ti, t, j), x2[ti][j], z);
 #pragma unroll
       for (int j = 0; j < 4; ++j) z[j] = act_fwd(act, z[j]);
       h2[0][t] = z;
@@ -191,7 +269,7 @@ static __global__ __launch_bounds__(64 * NRW_MAXW) void k_grad_narrow(const Grad
 #pragma unroll
         for (int ti = 0; ti < TH; ++ti)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) z = nrw_mfma(whf[l - 1][ti][t][j], h2[l - 1][ti][j], z);
+          for (int j = 0; j < 4; ++j) z = nrw_mfma(a_fh(l, ti, t, j), h2[l - 1][ti][j], z);
 #pragma unroll
         for (int j = 0; j < 4; ++j) z[j] = act_fwd(act, z[j]);
         h2[l][t] = z;
@@ -200,7 +278,7 @@ static __global__ __launch_bounds__(64 * NRW_MAXW) void k_grad_narrow(const Grad
 #pragma unroll
     for (int ti = 0; ti < TH; ++ti)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) zo = nrw_mfma(wlf[ti][j], h2[NH - 1][ti][j], zo);
+      for (int j = 0; j < 4; ++j) zo = nrw_mfma(a_fl(ti, j), h2[NH - 1][ti][j], zo);
 #pragma unroll
     for (int l = 0; l < NH; ++l)
 #pragma unroll
@@ -248,7 +326,7 @@ static __global__ __launch_bounds__(64 * NRW_MAXW) void k_grad_narrow(const Grad
     for (int ti = 0; ti < TH; ++ti) {
       f32x4 dh = {0, 0, 0, 0};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dh = nrw_mfma(wlb[ti][j], dz2[j], dh);
+      for (int j = 0; j < 4; ++j) dh = nrw_mfma(a_bl(ti, j), dz2[j], dh);
 #pragma unroll
       for (int j = 0; j < 4; ++j) dh[j] *= act_bwd(act, h2[NH - 1][ti][j]);
       dzh2[ti] = dh;
@@ -273,7 +351,7 @@ static __global__ __launch_bounds__(64 * NRW_MAXW) void k_grad_narrow(const Grad
 #pragma unroll
         for (int t = 0; t < TH; ++t)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) dh = nrw_mfma(whb[l - 1][ti][t][j], dzh2[t][j], dh);
+          for (int j = 0; j < 4; ++j) dh = nrw_mfma(a_bh(l, ti, t, j), dzh2[t][j], dh);
 #pragma unroll
         for (int j = 0; j < 4; ++j) dh[j] *= act_bwd(act, h2[l - 1][ti][j]);
         nx[ti] = dh;
@@ -306,7 +384,8 @@ static __global__ __launch_bounds__(64 * NRW_MAXW) void k_grad_narrow(const Grad
   dbl += nrw_xor16(dbl); dbl += nrw_xor32(dbl);
   ll_acc = wave_sum(ll_acc);
 
-  float *red = nrw_lds + LY::TRANS;
+  float *red = nrw_lds + LY::TRANS;                 // (WL: aliases the weight images -- every wave is past its tile loop first)
+  if constexpr (WL) __syncthreads();
   float *slab = p.slabs + ((size_t)e * p.S + s) * p.dp;
   // every wave but 0 parks its accumulators in turn; wave 0 adds them in wave order
   for (int w = 1; w < nw; ++w) {

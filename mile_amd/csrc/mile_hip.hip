@@ -88,15 +88,20 @@ static bool w64_supported(const mile_model_spec &sp) {
 }
 
 // the split-bf16 variant replaces the hidden->hidden products, so it needs at least one
-// k_grad_narrow: 1-3 hidden layers of width <= 32 and F <= 64, or 4-10 hidden layers of width <= 16 and F <= 16 (the depth
-// ablations of the reference: experiments/**: [16]*4 .. [16]*9 + [2], [8]*6 + [2]); <= 16 outputs (regression: exactly mu,
-// log sigma), any activation
+// k_grad_narrow: 1-3 hidden layers of width <= 64 and F <= 64 (<= 32: weights in registers; 33..64: weights in LDS), or 4-10
+// hidden layers of width <= 16 and F <= 16 (the depth ablations of the reference: experiments/**: [16]*4 .. [16]*9 + [2],
+// [8]*6 + [2]); <= 16 outputs (regression: exactly mu, log sigma), any activation
+static int narrow_tiles_hidden(const mile_model_spec &sp) {
+  int mw = 0;
+  for (int l = 0; l + 1 < sp.n_layers; ++l) mw = std::max(mw, sp.widths[l]);
+  return (mw + 15) / 16;
+}
 static bool narrow_supported(const mile_model_spec &sp) {
   if (sp.model != MILE_MODEL_FCN || !sp.use_bias) return false;
   const int nh = sp.n_layers - 1;
   if (nh < 1 || nh > 10 || sp.in_features > 64) return false;
   for (int l = 0; l < nh; ++l)
-    if (sp.widths[l] < 1 || sp.widths[l] > (nh > 3 ? 16 : 32)) return false;
+    if (sp.widths[l] < 1 || sp.widths[l] > (nh > 3 ? 16 : 64)) return false;
   if (nh > 3 && sp.in_features > 16) return false;
   const int K = sp.widths[nh];
   if (K < 1 || K > 16) return false;
@@ -186,6 +191,8 @@ static int generic_R(const DevSpec &ds) {
 // slab / llpart loops being 64 dependent global loads long.  E = 12, N = 1052 (66 tiles): 17 splits of 4 waves; E = 128: 8.
 static int narrow_S(const mile_sampler *s, int E) {
   const int tiles = (s->N + 15) / 16;
+  if (narrow_tiles_hidden(s->spec) >= 3)      // LDS-weight form: ~100 KB of images staged per workgroup -> one workgroup per CU
+    return std::max(1, std::min({64, s->n_cu / std::max(E, 1), std::max(1, tiles / NRW_MAXW)}));
   const int waves_per_particle = std::max(1, std::min(tiles, (16 * s->n_cu + std::max(E, 1) - 1) / std::max(E, 1)));
   return std::max(1, std::min(64, (waves_per_particle + NRW_MAXW - 1) / NRW_MAXW));
 }
@@ -486,7 +493,7 @@ int32_t mile_set_grad_kernel(mile_sampler *s, int32_t which) {
   if (!s) return fail(MILE_ERR_INVALID, "null handle");
   if (which < MILE_GRAD_AUTO || which > MILE_GRAD_MFMA_NARROW_F32) return fail(MILE_ERR_INVALID, "unknown grad kernel");
   if (which == MILE_GRAD_MFMA_NARROW_F32 && !narrow_supported(s->spec))
-    return fail(MILE_ERR_INVALID, "MFMA_NARROW_F32 needs an FCN with 1-3 hidden layers of width <= 32 and F <= 64 (or 4-10 of width <= 16 and F <= 16) and <= 16 outputs");
+    return fail(MILE_ERR_INVALID, "MFMA_NARROW_F32 needs an FCN with 1-3 hidden layers of width <= 64 and F <= 64 (or 4-10 of width <= 16 and F <= 16) and <= 16 outputs");
   if ((which == MILE_GRAD_MFMA_WIDE_BF16X3 || which == MILE_GRAD_MFMA_WIDE_BF16) && s->spec.model != MILE_MODEL_FCN)
     return fail(MILE_ERR_INVALID, "MFMA_WIDE_* are FCN kernels");
   if ((s->spec.model == MILE_MODEL_LENET) != (which == MILE_GRAD_LENET_F32 || which == MILE_GRAD_LENET_BF16) && which != MILE_GRAD_AUTO)
@@ -660,21 +667,31 @@ static bool fuse_ok(const mile_sampler *s, int kernel, const UpdParams &u) {
 
 template <int NH, int TH, int TF>
 static hipError_t launch_narrow_t(const GradParams &gp, int E, int nw, hipStream_t st) {
-  using LY = NarrowLayout<NH, TH, TF>;
-  k_grad_narrow<NH, TH, TF><<<dim3(gp.S, E), 64 * nw, LY::BYTES, st>>>(gp);
+  constexpr bool WL = TH >= 3;
+  using LY = NarrowLayout<NH, TH, TF, WL>;
+  if constexpr (WL) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void *)k_grad_narrow<NH, TH, TF, WL>, hipFuncAttributeMaxDynamicSharedMemorySize, LY::BYTES);
+      if (e != hipSuccess) return e;
+      attr_set = true;
+    }
+  }
+  k_grad_narrow<NH, TH, TF, WL><<<dim3(gp.S, E), 64 * nw, LY::BYTES, st>>>(gp);
   return hipGetLastError();
 }
 static hipError_t launch_narrow(const mile_sampler *s, const GradParams &gp, int E, hipStream_t st) {
   const int nh = s->spec.n_layers - 1;
-  int mw = 0;
-  for (int l = 0; l < nh; ++l) mw = std::max(mw, s->spec.widths[l]);
-  const int th = mw <= 16 ? 1 : 2, tf = s->spec.in_features <= 16 ? 1 : 4;
-  const int nw = narrow_waves(s, gp.S, gp.N);
+  const int th = narrow_tiles_hidden(s->spec), tf = s->spec.in_features <= 16 ? 1 : 4;
+  const int nw = th >= 3 ? NRW_MAXW : narrow_waves(s, gp.S, gp.N);
 #define MILE_NRW(NH_, TH_, TF_) if (nh == NH_ && th == TH_ && tf == TF_) return launch_narrow_t<NH_, TH_, TF_>(gp, E, nw, st);
   MILE_NRW(1, 1, 1) MILE_NRW(1, 2, 1) MILE_NRW(1, 1, 4) MILE_NRW(1, 2, 4)
   MILE_NRW(2, 1, 1) MILE_NRW(2, 2, 1) MILE_NRW(2, 1, 4) MILE_NRW(2, 2, 4)
   MILE_NRW(3, 1, 1) MILE_NRW(3, 2, 1) MILE_NRW(3, 1, 4) MILE_NRW(3, 2, 4)
   MILE_NRW(4, 1, 1) MILE_NRW(5, 1, 1) MILE_NRW(6, 1, 1) MILE_NRW(7, 1, 1) MILE_NRW(8, 1, 1) MILE_NRW(9, 1, 1) MILE_NRW(10, 1, 1)
+  MILE_NRW(1, 3, 1) MILE_NRW(1, 4, 1) MILE_NRW(1, 3, 4) MILE_NRW(1, 4, 4)      // hidden widths 33..64: weights in LDS
+  MILE_NRW(2, 3, 1) MILE_NRW(2, 4, 1) MILE_NRW(2, 3, 4) MILE_NRW(2, 4, 4)
+  MILE_NRW(3, 3, 1) MILE_NRW(3, 4, 1) MILE_NRW(3, 3, 4) MILE_NRW(3, 4, 4)
 #undef MILE_NRW
   return hipErrorInvalidValue;
 }
@@ -1679,8 +1696,9 @@ int32_t mile_grad_launch_info(const mile_sampler *s, int32_t E, int32_t *grid_x,
                   : (fq == 1 ? w64_lds_bytes<3, 1, true>() : w64_lds_bytes<3, 2, true>());
   } else if (kernel == MILE_GRAD_MFMA_NARROW_F32) {
     nm = "k_grad_narrow";
-    if (block) *block = 64 * narrow_waves(s, S, s->N);
-    lds = std::max(NarrowLayout<3, 2, 4>::BYTES, NarrowLayout<10, 1, 1>::BYTES);   // upper bound over the instantiations
+    if (block) *block = 64 * (narrow_tiles_hidden(s->spec) >= 3 ? NRW_MAXW : narrow_waves(s, S, s->N));
+    lds = narrow_tiles_hidden(s->spec) >= 3 ? NarrowLayout<3, 4, 4, true>::BYTES      // upper bounds over the instantiations
+                                            : std::max(NarrowLayout<3, 2, 4>::BYTES, NarrowLayout<10, 1, 1>::BYTES);
   } else if (kernel == MILE_GRAD_LENET_BF16) {
     nm = "k_conv5m_fwd/dx/dw (implicit-GEMM bf16 MFMA) + k_mm3 (Dense, fp32-faithful three-term products)";
     lds = (int)cm_lds_dw(CM_IN8, s->lg.hp1, s->lg.wp1, 0);

@@ -825,7 +825,8 @@ LPPD_GATE_CASES = [
     # same kernel, and a width only the generic kernel covers
     (5, (16, 16, 2), 'relu', 'regr', 200, 4, 60, 3.0, 'mfma_narrow_f32'),
     (54, (32, 7), 'sigmoid', 'classification', 400, 4, 60, 1.0, 'mfma_narrow_f32'),
-    (5, (40, 40, 2), 'relu', 'regr', 200, 4, 60, 3.0, 'generic'),
+    (5, (72, 72, 2), 'relu', 'regr', 200, 4, 60, 3.0, 'generic'),
+    (5, (64, 64, 3), 'tanh', 'classification', 300, 4, 60, 1.0, 'mfma_narrow_f32'),     # widths 33..64: the LDS-weight form
     # BASELINE config B1 (airfoil shape, 3x64 MLP, 16 particles) on the kernel AUTO selects
     (5, (64, 64, 64, 2), 'relu', 'regr', 1052, 16, 120, 1.0, 'mfma_w64_bf16x3'),
     # the layer-wise MFMA GEMM path on a small softmax net (B4's head)
