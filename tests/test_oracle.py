@@ -104,6 +104,44 @@ def test_b_step_invariants_and_closed_form():
     assert np.abs(dK - (d - 1) * (delta - math.log(2) + np.log(1 + zeta**2))).max() < 1e-10
 
 
+def test_b_step_is_the_exact_flow_of_the_esh_momentum_equation():
+    """A check of the restated B-step that does not lean on the recollection of blackjax's text.  For a frozen gradient g the
+    ESH / MCLMC momentum obeys du/dt = (|g| / (d - 1)) (e - (u.e) u), e = g / |g| (Robnik et al., Microcanonical HMC; the
+    equation blackjax integrates), whose solution is what `esh_dynamics_momentum_update_one_step` evaluates in closed form.  An
+    exact flow map must (i) compose: B(t1) then B(t2) == B(t1 + t2), for the momentum AND the accumulated kinetic-energy change
+    (a wrong coefficient anywhere in the formula breaks this); (ii) have the equation's right-hand side as its derivative at
+    t = 0; (iii) change the kinetic energy at the rate of the work done along the velocity, d(dK)/dt = g.u -- the term that
+    cancels d(log density)/dt = g.u of the position update, i.e. energy conservation to first order."""
+    rng = np.random.default_rng(5)
+    E, d = 5, 37
+    u, g = _rand_unit(rng, E, d), 12.0 * rng.standard_normal((E, d))
+    one = np.ones(E)
+    t1, t2 = 0.23, 0.41
+    u1, _, k1 = O.esh_momentum_update(u, g, t1 * one, 1.0)
+    u12, _, k2 = O.esh_momentum_update(u1, g, t2 * one, 1.0)
+    ud, _, kd = O.esh_momentum_update(u, g, (t1 + t2) * one, 1.0)
+    assert np.abs(u12 - ud).max() < 1e-13 and np.abs(k1 + k2 - kd).max() < 1e-11
+    # the coefficient multiplies the time: B(eps, c) == B(eps c, 1)
+    uc, _, kc = O.esh_momentum_update(u, g, one * 0.9, 0.37)
+    ue_, _, ke_ = O.esh_momentum_update(u, g, one * 0.9 * 0.37, 1.0)
+    assert np.abs(uc - ue_).max() < 1e-15 and np.abs(kc - ke_).max() < 1e-12
+    # derivative at 0 (central difference of the flow at +-h; the flow at -h is the inverse map)
+    h = 1e-5
+    up, _, kp = O.esh_momentum_update(u, g, h * one, 1.0)
+    um, _, km = O.esh_momentum_update(u, g, -h * one, 1.0)
+    gn = np.linalg.norm(g, axis=1, keepdims=True)
+    e = g / gn
+    rhs = gn / (d - 1) * (e - (u * e).sum(1, keepdims=True) * u)
+    assert np.abs((up - um) / (2 * h) - rhs).max() < 1e-7 * np.abs(rhs).max()
+    assert np.abs((kp - km) / (2 * h) - (g * u).sum(1)).max() < 1e-6 * np.abs((g * u).sum(1)).max()
+    # and the O-step leaves the momentum on the unit sphere while nu -> sqrt(2 h / (L d)) for h << L (the Langevin limit)
+    z = rng.standard_normal((E, d))
+    uo = O.partial_refresh(u, z, 1e-6 * one, 3.0 * one)
+    assert np.abs(np.linalg.norm(uo, axis=1) - 1).max() < 1e-14
+    nu = math.sqrt(2e-6 / (3.0 * d))
+    assert np.abs((uo - u) - nu * (z - (u * z).sum(1, keepdims=True) * u)).max() < 5e-3 * nu
+
+
 def _gauss_target(th):
     return -0.5 * (th * th).sum(axis=1), -th
 
