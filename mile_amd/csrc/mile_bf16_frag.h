@@ -57,6 +57,40 @@ __device__ __forceinline__ void store_tile(char *img, int col0, const f32x16 &ac
   }
 }
 
+// ---- padded images (k_grad_w128b) ---------------------------------------------------------------------------------------
+// Same two kinds of read, but every address is (one per-lane base) + (a compile-time constant), so the constant rides in the
+// ds instruction's offset field: the XOR swizzle above needs a separate address register for every (k-step, column block)
+// pair -- ~30 registers of addresses in k_grad_w128b, which the compiler parked in AGPRs / scratch and rebuilt with ~280
+// v_add / v_accvgpr_read per tile pair.  Rows are 272 bytes (256 + one 16-byte chunk of padding) and logical row i of each
+// 16-row group sits at physical row pim_row(i): i = 8h + 4t + q  ->  4q + 2h + t.
+//   * row reads (ds_read_b128, 16-lane service groups): 272 = 68 dwords = 4 mod 64, and the 16 lanes of a group hold 16
+//     distinct physical rows mod 16 -> 16 x 4 distinct banks;
+//   * transposed reads (ds_read_b64_tr_b16, 32-lane groups): the 4 rows one read covers (q = 0..3 at fixed h, t) are
+//     4 physical rows apart = 16 dwords mod 64 apart, each 16 dwords wide -> 64 distinct banks; the two reads of a
+//     fragment (t = 0, 1) are adjacent physical rows.
+#define PIM_STRIDE 272
+__device__ __forceinline__ int pim_row(int i) { return (i & ~15) | ((i & 3) << 2) | (((i >> 3) & 1) << 1) | ((i >> 2) & 1); }
+__device__ __forceinline__ int pim_off(int row, int ch) { return PIM_STRIDE * pim_row(row) + 16 * ch; }
+// per-lane base of a transposed read (add PIM_STRIDE * row0 + 2 * col0, row0 a multiple of 16, col0 of 32)
+__device__ __forceinline__ int pim_tr_base(int lane) {
+  const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
+  return PIM_STRIDE * (4 * q + 2 * h) + 32 * g1 + 16 * (p >> 1) + 8 * (p & 1);
+}
+// element j of lane (r, h) = image[row0 + 8h + j][col0 + r]; `a` = image + pim_tr_base(lane) + PIM_STRIDE * row0 + 2 * col0
+__device__ __forceinline__ bf16x8 pim_tr_frag(const char *a) {
+  const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, a));
+  const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, a + PIM_STRIDE));
+  return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// two fp32 -> one packed bf16 pair (round to nearest even) in ONE v_cvt_pk_bf16_f32: the 2-vector conversion selects the
+// packed instruction, the 4-vector one lowers to one conversion per element plus a v_perm_b32 per pair.  (Not inline asm:
+// the operands are usually fresh MFMA results, and the MFMA -> VALU wait states are inserted by the compiler only for
+// instructions it can see.)
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
 __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }

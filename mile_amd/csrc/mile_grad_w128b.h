@@ -39,16 +39,19 @@
 
 template <int NH, int RT>
 struct W128Layout {
-  static constexpr int WIMG = 0;                              // W_2..W_NH: [128 in][128 out] bf16, 32 KiB each
-  static constexpr int TILE = WIMG + (NH - 1) * 32768;        // per row tile: H_1..H_NH, dZ ping-pong ([32][128] each)
+  static constexpr int IMG = 32 * PIM_STRIDE;                 // one [32 rows][128] bf16 tile image (padded rows, mile_bf16_frag.h)
+  static constexpr int WBYTES = 128 * PIM_STRIDE;             // one [128 in][128 out] bf16 weight image
+  static constexpr int TILE = 0;                              // per row tile: H_1..H_NH, dZ ping-pong
   static constexpr int HIMG = 0;                              //   offsets inside a tile set
-  static constexpr int DZ = NH * 8192;
-  static constexpr int TILE_BYTES = (NH + 2) * 8192;
-  static constexpr int BIAS = TILE + RT * TILE_BYTES;         // bias tiles in accumulator layout: [NH][4 waves][2 halves][16] fp32
+  static constexpr int DZ = NH * IMG;
+  static constexpr int TILE_BYTES = (NH + 2) * IMG;
+  static constexpr int WIMG = TILE + RT * TILE_BYTES;         // W_2..W_NH
+  static constexpr int BIAS = WIMG + (NH - 1) * WBYTES;       // bias tiles in accumulator layout: [NH][4 waves][2 halves][16] fp32
   static constexpr int PART = BIAS + NH * 4 * 2 * 16 * 4;     // head partial sums: [RT][4 waves][32 rows][2] fp32
   static constexpr int DOP = PART + RT * 4 * 32 * 2 * 4;      // per-wave transposed d(out): [4 waves][RT][2][32 rows] bf16
   static constexpr int ZERO = DOP + 4 * RT * 2 * 32 * 2;      // 16 zero bytes
   static constexpr int BYTES = ZERO + 16;
+  static_assert(BYTES <= 160 * 1024, "k_grad_w128b: LDS budget");
 };
 
 // Workgroup barrier for LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the global
@@ -70,33 +73,38 @@ __device__ __forceinline__ float row_loss_regr_fast(float mu, float sr, float yv
   return ll;
 }
 
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 // H = relu(z) as bf16 into the image: rounding and ReLU commute, and on bf16 bit patterns ReLU is a signed
-// 16-bit max with 0 (v_pk_max_i16), two elements per instruction.
-__device__ __forceinline__ void store_tile_relu(char *img, int col0, const f32x16 &z, int lane, s16x4 packed[4]) {
-  const int r = lane & 31, h = lane >> 5;
+// 16-bit max with 0 (v_pk_max_i16), two elements per instruction.  dst = image + this lane's store base
+// (row pim_row(r), column 32 w + 4 h); group g of 4 features sits 16 g bytes further.
+__device__ __forceinline__ void store_tile_relu(char *dst, const f32x16 &z, uint32_t packed[8]) {
+  const s16x2 zero = {0, 0};
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    const f32x4_t v = {z[4 * g], z[4 * g + 1], z[4 * g + 2], z[4 * g + 3]};
-    const s16x4 b = __builtin_bit_cast(s16x4, __builtin_convertvector(v, bf16x4));
-    const s16x4 zero = {0, 0, 0, 0};
-    packed[g] = __builtin_elementwise_max(b, zero);
-    *reinterpret_cast<s16x4 *>(img + img_off(r, (col0 >> 3) + g) + 8 * h) = packed[g];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const uint32_t b = cvt_pk_bf16(z[4 * g + 2 * k], z[4 * g + 2 * k + 1]);
+      packed[2 * g + k] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, b), zero));
+    }
+    const u32x2_t o = {packed[2 * g], packed[2 * g + 1]};
+    *reinterpret_cast<u32x2_t *>(dst + 16 * g) = o;
   }
 }
 
 // one 4-feature group of a masked dZ store; hb = this lane's 4 H values (bit patterns) of that group
 __device__ __forceinline__ void store_group_masked(char *dst, const f32x4_t v, const f32x2_t hb) {
   const uint32_t ones = 0x00010001u;
-  const f32x2_t b = __builtin_bit_cast(f32x2_t, __builtin_convertvector(v, bf16x4));
   f32x2_t o;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
+    const uint32_t b = cvt_pk_bf16(v[2 * k], v[2 * k + 1]);
     float m, t;
     asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(hb[k]), "v"(ones));
-    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(t) : "v"(b[k]), "v"(m));
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(t) : "v"(b), "v"(m));
     o[k] = t;
   }
   *reinterpret_cast<f32x2_t *>(dst) = o;
@@ -116,11 +124,17 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
   const bf16 *Xb = reinterpret_cast<const bf16 *>(p.Xb);
   const bf16 *Xt = reinterpret_cast<const bf16 *>(p.Xt);
   const float *yv = reinterpret_cast<const float *>(p.y);
+  // per-lane LDS bases; everything else in an address is a compile-time constant (mile_bf16_frag.h, padded images)
+  const char *rb = lds + PIM_STRIDE * pim_row(r) + 16 * h;              // row reads of a tile image: + image + 32 s
+  char *sb = lds + PIM_STRIDE * pim_row(r) + 64 * w + 8 * h;            // stores / mask reads, this wave's features: + image + 16 g
+  const char *tb = lds + pim_tr_base(lane);                             // transposed reads: + image + PIM_STRIDE row0 + 2 col0
+  const char *tbw = tb + 64 * w;                                        //   ... of this wave's column block
+  const char *wb = rb + PIM_STRIDE * 32 * w;                            // weight rows 32 w + r (backward form): + image + 32 s
 
   // ---- stage the weights as bf16 images -----------------------------------------------------
 #pragma unroll
   for (int li = 1; li < NH; ++li) {
-    char *img = lds + LY::WIMG + (li - 1) * 32768;
+    char *img = lds + LY::WIMG + (li - 1) * LY::WBYTES;
     const float *W = th + sp.w_off[li];
     for (int c = tid; c < 128 * 16; c += 256) {
       const int row = c >> 4, ch = c & 15;
@@ -128,7 +142,7 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
       bf16x8 v;
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = (bf16)src[j];
-      *reinterpret_cast<bf16x8 *>(img + img_off(row, ch)) = v;
+      *reinterpret_cast<bf16x8 *>(img + pim_off(row, ch)) = v;
     }
   }
   // head weights as register fragments.  Forward: the wave's own H tile is used straight from the
@@ -187,14 +201,19 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
   }
   float ll_acc = 0.0f;
   unsigned tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;   // TIMING: cycles per phase (dev builds only; wave-uniform -> SGPRs)
+  auto now_cycles = [&]() -> unsigned {   // s_memtime into an SGPR pair: the stamps must not cost vector registers
+    unsigned long long tm;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm)::"memory");
+    return (unsigned)tm;
+  };
   auto tick = [&](int k) {
     if (TIMING) {
-      const unsigned now = (unsigned)__builtin_readcyclecounter();
+      const unsigned now = now_cycles();
       tph[k] += now - tlast;
       tlast = now;
     }
   };
-  if (TIMING) tlast = (unsigned)__builtin_readcyclecounter();
+  if (TIMING) tlast = now_cycles();
 
   const int NBS = p.Npb / (32 * RT);   // super tiles of RT row tiles
   const int nb0 = (int)((long long)sidx * NBS / p.S), nb1 = (int)((long long)(sidx + 1) * NBS / p.S);
@@ -245,7 +264,6 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
           y_cur[q] = yv[row0 + r < p.N ? row0 + r : 0];
         }
       } else {
-        const char *Wimg = lds + LY::WIMG + (l - 1) * 32768;
         // all fragment reads of the phase are issued before the first MFMA: with one wave per SIMD nothing
         // else hides the LDS latency, and read-then-use pairs would pay it once per MFMA
         bf16x8 bfr[RT][8];
@@ -254,24 +272,23 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
         for (int s = 0; s < 8; ++s)
 #pragma unroll
           for (int q = 0; q < RT; ++q)
-            bfr[q][s] = row_frag(lds + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + (l - 1) * 8192, r, 2 * s + h);
+            bfr[q][s] = *reinterpret_cast<const bf16x8 *>(rb + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + (l - 1) * LY::IMG + 32 * s);
         __builtin_amdgcn_sched_barrier(0);   // keep the reads above, the MFMAs below
 #pragma unroll
         for (int s = 0; s < 8; ++s)
 #pragma unroll
           for (int q = 0; q < RT; ++q) acc[q] = mfma_bf16(afp[s], bfr[q][s], s == 0 ? bl : acc[q]);
-        (void)Wimg;
       }
 #pragma unroll
       for (int q = 0; q < RT; ++q) {
-        s16x4 pk[4];
-        store_tile_relu(lds + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + l * 8192, 32 * w, acc[q], lane, pk);
+        uint32_t pk[8];
+        store_tile_relu(sb + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + l * LY::IMG, acc[q], pk);
         if (l == NH - 1) {   // head, this wave's 32 of the 128 features: partial (mu, log sigma) per row
           f32x16 zero16, part;
 #pragma unroll
           for (int j = 0; j < 16; ++j) zero16[j] = 0.0f;
-          const bf16x8 b0 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(pk[0], pk[1], 0, 1, 2, 3, 4, 5, 6, 7));
-          const bf16x8 b1 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(pk[2], pk[3], 0, 1, 2, 3, 4, 5, 6, 7));
+          const u32x4_t p0 = {pk[0], pk[1], pk[2], pk[3]}, p1 = {pk[4], pk[5], pk[6], pk[7]};
+          const bf16x8 b0 = __builtin_bit_cast(bf16x8, p0), b1 = __builtin_bit_cast(bf16x8, p1);
           part = mfma_bf16(woF[0], b0, zero16);
           part = mfma_bf16(woF[1], b1, part);
           if (h == 0) {
@@ -282,7 +299,7 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
       }
       if (l + 1 < NH) {   // weights of layer l + 1 (image l), forward form
 #pragma unroll
-        for (int s = 0; s < 8; ++s) afp[s] = tr_frag(lds + LY::WIMG + l * 32768, 16 * s, 32 * w, lane);
+        for (int s = 0; s < 8; ++s) afp[s] = pim_tr_frag(tbw + LY::WIMG + l * LY::WBYTES + PIM_STRIDE * 16 * s);
         __builtin_amdgcn_sched_barrier(0);
       }
       lds_barrier();
@@ -295,20 +312,18 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
       f32x16 zero16;
 #pragma unroll
       for (int j = 0; j < 16; ++j) zero16[j] = 0.0f;
-      int offg[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) offg[g] = img_off(r, 4 * w + g) + 8 * h;
       f32x2_t pr[RT][4], hm[RT][4];
       bf16x8 ah[RT][2];
 #pragma unroll
       for (int q = 0; q < RT; ++q) {
-        const char *Hin = lds + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + (NH - 1) * 8192;
+        constexpr int HOFF = LY::TILE + LY::HIMG + (NH - 1) * LY::IMG;
+        const int Hin = HOFF + q * LY::TILE_BYTES;
 #pragma unroll
         for (int ww = 0; ww < 4; ++ww) pr[q][ww] = *reinterpret_cast<const f32x2_t *>(lds + LY::PART + ((q * 4 + ww) * 32 + r) * 8);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) hm[q][g] = *reinterpret_cast<const f32x2_t *>(Hin + offg[g]);
+        for (int g = 0; g < 4; ++g) hm[q][g] = *reinterpret_cast<const f32x2_t *>(sb + Hin + 16 * g);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) ah[q][s] = tr_frag(Hin, 16 * s, 32 * w, lane);
+        for (int s = 0; s < 2; ++s) ah[q][s] = pim_tr_frag(tbw + Hin + PIM_STRIDE * 16 * s);
       }
       if (NH == 1) prefetch_x();
       __builtin_amdgcn_sched_barrier(0);
@@ -335,7 +350,6 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
       }
 #pragma unroll
       for (int q = 0; q < RT; ++q) {
-        char *ts = lds + LY::TILE + q * LY::TILE_BYTES;
         const char *dop = lds + LY::DOP + (w * RT + q) * 128;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -347,12 +361,12 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4_t v = {acc[q][4 * g], acc[q][4 * g + 1], acc[q][4 * g + 2], acc[q][4 * g + 3]};
-          store_group_masked(ts + LY::DZ + offg[g], v, hm[q][g]);
+          store_group_masked(sb + LY::TILE + q * LY::TILE_BYTES + LY::DZ + 16 * g, v, hm[q][g]);
         }
       }
       if (NH >= 2) {   // weights of the last hidden layer, backward form
 #pragma unroll
-        for (int s = 0; s < 8; ++s) afp[s] = row_frag(lds + LY::WIMG + (NH - 2) * 32768, 32 * w + r, 2 * s + h);
+        for (int s = 0; s < 8; ++s) afp[s] = *reinterpret_cast<const bf16x8 *>(wb + LY::WIMG + (NH - 2) * LY::WBYTES + 32 * s);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -365,26 +379,21 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
     int pp = 0;
 #pragma unroll
     for (int l = NH - 1; l >= 1; --l) {   // dZ of layer l is in DZ[pp]; its input is H_l (image l-1)
-      const char *Wimg = lds + LY::WIMG + (l - 1) * 32768;
       f32x16 zero16;
 #pragma unroll
       for (int j = 0; j < 16; ++j) zero16[j] = 0.0f;
       bf16x8 bfr[RT][8], bq[RT][2], ah[RT][2][4];
       f32x2_t hm[RT][4];
-      int offg[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) offg[g] = img_off(r, 4 * w + g) + 8 * h;
 #pragma unroll
       for (int s = 0; s < 8; ++s)
 #pragma unroll
         for (int q = 0; q < RT; ++q)
-          bfr[q][s] = row_frag(lds + LY::TILE + q * LY::TILE_BYTES + LY::DZ + pp * 8192, r, 2 * s + h);
-      (void)Wimg;
+          bfr[q][s] = *reinterpret_cast<const bf16x8 *>(rb + LY::TILE + q * LY::TILE_BYTES + LY::DZ + pp * LY::IMG + 32 * s);
 #pragma unroll
       for (int q = 0; q < RT; ++q)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          hm[q][g] = *reinterpret_cast<const f32x2_t *>(lds + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + (l - 1) * 8192 + offg[g]);
+          hm[q][g] = *reinterpret_cast<const f32x2_t *>(sb + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + (l - 1) * LY::IMG + 16 * g);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
@@ -392,13 +401,13 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
         for (int q = 0; q < RT; ++q) acc[q] = mfma_bf16(afp[s], bfr[q][s], s == 0 ? zero16 : acc[q]);
         {
           const int q = (s * RT) / 8, sub = RT == 2 ? (s & 3) : (s >> 1);   // RT = 1: four steps carry reads
-          const char *ts = lds + LY::TILE + q * LY::TILE_BYTES;
-          const char *dz = ts + LY::DZ + pp * 8192, *Hin = ts + LY::HIMG + (l - 1) * 8192;
+          const int ts = LY::TILE + q * LY::TILE_BYTES;
+          const int dz = ts + LY::DZ + pp * LY::IMG, Hin = ts + LY::HIMG + (l - 1) * LY::IMG, R16 = PIM_STRIDE * 16;
           if (RT == 2 || (s & 1) == 0) {
-            if (sub == 0) { bq[q][0] = tr_frag(dz, 0, 32 * w, lane); ah[q][0][0] = tr_frag(Hin, 0, 0, lane); ah[q][0][1] = tr_frag(Hin, 0, 32, lane); }
-            if (sub == 1) { ah[q][0][2] = tr_frag(Hin, 0, 64, lane); ah[q][0][3] = tr_frag(Hin, 0, 96, lane); bq[q][1] = tr_frag(dz, 16, 32 * w, lane); }
-            if (sub == 2) { ah[q][1][0] = tr_frag(Hin, 16, 0, lane); ah[q][1][1] = tr_frag(Hin, 16, 32, lane); }
-            if (sub == 3) { ah[q][1][2] = tr_frag(Hin, 16, 64, lane); ah[q][1][3] = tr_frag(Hin, 16, 96, lane); }
+            if (sub == 0) { bq[q][0] = pim_tr_frag(tbw + dz); ah[q][0][0] = pim_tr_frag(tb + Hin); ah[q][0][1] = pim_tr_frag(tb + Hin + 64); }
+            if (sub == 1) { ah[q][0][2] = pim_tr_frag(tb + Hin + 128); ah[q][0][3] = pim_tr_frag(tb + Hin + 192); bq[q][1] = pim_tr_frag(tbw + dz + R16); }
+            if (sub == 2) { ah[q][1][0] = pim_tr_frag(tb + Hin + R16); ah[q][1][1] = pim_tr_frag(tb + Hin + R16 + 64); }
+            if (sub == 3) { ah[q][1][2] = pim_tr_frag(tb + Hin + R16 + 128); ah[q][1][3] = pim_tr_frag(tb + Hin + R16 + 192); }
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -409,7 +418,7 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
       }
 #pragma unroll
       for (int q = 0; q < RT; ++q) {
-        char *dzo = lds + LY::TILE + q * LY::TILE_BYTES + LY::DZ + (pp ^ 1) * 8192;
+        char *dzo = sb + LY::TILE + q * LY::TILE_BYTES + LY::DZ + (pp ^ 1) * LY::IMG;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
@@ -418,7 +427,7 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
             if (ib & 1) {
               const int g = 2 * s + (ib >> 1);
               const f32x4_t v = {acc[q][4 * g], acc[q][4 * g + 1], acc[q][4 * g + 2], acc[q][4 * g + 3]};
-              store_group_masked(dzo + offg[g], v, hm[q][g]);
+              store_group_masked(dzo + 16 * g, v, hm[q][g]);
             }
           }
           db[l] = bf16_colsum(bq[q][s], db[l]);
@@ -428,7 +437,7 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
       pp ^= 1;
       if (l >= 2) {   // weights of the next layer down, backward form
 #pragma unroll
-        for (int s = 0; s < 8; ++s) afp[s] = row_frag(lds + LY::WIMG + (l - 2) * 32768, 32 * w + r, 2 * s + h);
+        for (int s = 0; s < 8; ++s) afp[s] = *reinterpret_cast<const bf16x8 *>(wb + LY::WIMG + (l - 2) * LY::WBYTES + 32 * s);
         __builtin_amdgcn_sched_barrier(0);
       }
       lds_barrier();
@@ -437,11 +446,10 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
     // ---- backward: first layer ------------------------------------------------------------------------
 #pragma unroll
     for (int q = 0; q < RT; ++q) {
-      const char *dz = lds + LY::TILE + q * LY::TILE_BYTES + LY::DZ + pp * 8192;
-      const int row0 = 32 * (t * RT + q);
+      const char *dz = tbw + LY::TILE + q * LY::TILE_BYTES + LY::DZ + pp * LY::IMG;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const bf16x8 bq = tr_frag(dz, 16 * s, 32 * w, lane);
+        const bf16x8 bq = pim_tr_frag(dz + PIM_STRIDE * 16 * s);
         dW1 = mfma_bf16(xt_cur[q][s], bq, dW1);
         db[0] = bf16_colsum(bq, db[0]);
       }
