@@ -69,6 +69,15 @@ __device__ __forceinline__ void store_tile(char *img, int col0, const f32x16 &ac
 //     4 physical rows apart = 16 dwords mod 64 apart, each 16 dwords wide -> 64 distinct banks; the two reads of a
 //     fragment (t = 0, 1) are adjacent physical rows.
 #define PIM_STRIDE 272
+typedef uint32_t u32x4_lab __attribute__((ext_vector_type(4)));
+// 16-byte row read of a padded image
+__device__ __forceinline__ bf16x8 pim_row_read(const char *a) {
+#ifdef MILE_LAB_NO_ROW   // dev experiment (tools/r03/lab)
+  const u32x4_lab v = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};   // one hoisted constant: no VALU added
+  return __builtin_bit_cast(bf16x8, v);
+#endif
+  return *reinterpret_cast<const bf16x8 *>(a);
+}
 __device__ __forceinline__ int pim_row(int i) { return (i & ~15) | ((i & 3) << 2) | (((i >> 3) & 1) << 1) | ((i >> 2) & 1); }
 __device__ __forceinline__ int pim_off(int row, int ch) { return PIM_STRIDE * pim_row(row) + 16 * ch; }
 // per-lane base of a transposed read (add PIM_STRIDE * row0 + 2 * col0, row0 a multiple of 16, col0 of 32)
@@ -78,6 +87,10 @@ __device__ __forceinline__ int pim_tr_base(int lane) {
 }
 // element j of lane (r, h) = image[row0 + 8h + j][col0 + r]; `a` = image + pim_tr_base(lane) + PIM_STRIDE * row0 + 2 * col0
 __device__ __forceinline__ bf16x8 pim_tr_frag(const char *a) {
+#ifdef MILE_LAB_NO_TR   // dev experiment (tools/r03/lab)
+  const u32x4_lab v = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};   // one hoisted constant: no VALU added
+  return __builtin_bit_cast(bf16x8, v);
+#endif
   const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, a));
   const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, a + PIM_STRIDE));
   return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -92,7 +105,13 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
 }
 
 __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+#ifdef MILE_LAB_NO_MFMA   // dev experiment (tools/r03/lab): what the kernel costs without its matrix products
+  f32x16 o = c;
+  o[0] += (float)a[0] + (float)b[0];
+  return o;
+#else
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
 }
 
 __device__ __forceinline__ float bf16_colsum(const bf16x8 v, float acc) {   // acc + sum of the 8 elements

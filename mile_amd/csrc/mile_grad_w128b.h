@@ -56,7 +56,11 @@ struct W128Layout {
 
 // Workgroup barrier for LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the global
 // prefetches (X, y of the next tile pair) that are deliberately in flight across it.
+#ifdef MILE_LAB_NO_BARRIER   // dev experiment (tools/r03/lab): wrong results, shows what the synchronisation costs
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 
 // row_loss_regr with the hardware exp / log / reciprocal (1 ulp-class, ~1e-6 relative): the head sits alone on
 // the critical path between two barriers, and next to bf16 operands (2^-9) the difference is invisible.
@@ -78,21 +82,18 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
-// H = relu(z) as bf16 into the image: rounding and ReLU commute, and on bf16 bit patterns ReLU is a signed
-// 16-bit max with 0 (v_pk_max_i16), two elements per instruction.  dst = image + this lane's store base
-// (row pim_row(r), column 32 w + 4 h); group g of 4 features sits 16 g bytes further.
-__device__ __forceinline__ void store_tile_relu(char *dst, const f32x16 &z, uint32_t packed[8]) {
+// H = relu(z) as bf16 into the image, one 4-feature group: rounding and ReLU commute, and on bf16 bit patterns ReLU
+// is a signed 16-bit max with 0 (v_pk_max_i16), two elements per instruction.  dst = image + this lane's store base
+// (row pim_row(r), column 32 w + 4 h) + 16 g.
+__device__ __forceinline__ void store_group_relu(char *dst, float z0, float z1, float z2, float z3, uint32_t &p0, uint32_t &p1) {
   const s16x2 zero = {0, 0};
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const uint32_t b = cvt_pk_bf16(z[4 * g + 2 * k], z[4 * g + 2 * k + 1]);
-      packed[2 * g + k] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, b), zero));
-    }
-    const u32x2_t o = {packed[2 * g], packed[2 * g + 1]};
-    *reinterpret_cast<u32x2_t *>(dst + 16 * g) = o;
-  }
+  p0 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, cvt_pk_bf16(z0, z1)), zero));
+  p1 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, cvt_pk_bf16(z2, z3)), zero));
+  const u32x2_t o = {p0, p1};
+#ifdef MILE_LAB_NO_STORE   // dev experiment (tools/r03/lab)
+  if (p0 != 0x12345u) return;
+#endif
+  *reinterpret_cast<u32x2_t *>(dst) = o;
 }
 
 // one 4-feature group of a masked dZ store; hb = this lane's 4 H values (bit patterns) of that group
@@ -107,6 +108,9 @@ __device__ __forceinline__ void store_group_masked(char *dst, const f32x4_t v, c
     asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(t) : "v"(b), "v"(m));
     o[k] = t;
   }
+#ifdef MILE_LAB_NO_STORE
+  if (o[0] != 123.0f) return;
+#endif
   *reinterpret_cast<f32x2_t *>(dst) = o;
 }
 
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
       for (int j = 0; j < 8; ++j)
         woF[s2][j] = (bf16)(r < 2 ? Wo[(32 * w + 16 * s2 + 8 * (j >> 2) + 4 * h + (j & 3)) * 2 + r] : 0.0f);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) woB[j] = (bf16)((h == 0 && j < 2) ? Wo[(32 * w + r) * 2 + j] : 0.0f);
+    for (int j = 0; j < 8; ++j) woB[j] = (bf16)(j < 2 ? Wo[(32 * w + r) * 2 + j] : 0.0f);   // both lane halves: see the head
     if (tid < 4) reinterpret_cast<float *>(lds + LY::ZERO)[tid] = 0.0f;
   }
   // first-layer weights: one A fragment per wave, A[m = out 32w + r][k = in 8h + j], kept in registers
@@ -218,135 +222,202 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
   const int NBS = p.Npb / (32 * RT);   // super tiles of RT row tiles
   const int nb0 = (int)((long long)sidx * NBS / p.S), nb1 = (int)((long long)(sidx + 1) * NBS / p.S);
 
-  // Global operands are fetched a phase (X: an iteration) ahead of their use: with one wave per SIMD a global
-  // load issued where it is needed costs its full ~2000-cycle latency every tile pair.
+  // Global operands are fetched a whole tile pair ahead of their use, right after the registers' previous contents are
+  // consumed at the top of the loop: with one wave per SIMD nothing hides a global load, and these took > 2000 cycles to
+  // land even from L2 (measured: requested one phase ahead, the top of the loop still waited ~1000 cycles per pair).
+  // lane (r, h) holds the target of row r of tile h.
   bf16x8 xb_next[RT];
+  float y_next;
 #pragma unroll
   for (int q = 0; q < RT; ++q) {
     const int rowc = 32 * (nb0 < nb1 ? nb0 * RT + q : 0);
     xb_next[q] = *reinterpret_cast<const bf16x8 *>(Xb + (size_t)(rowc + r) * 16 + 8 * h);
   }
-  for (int t = nb0; t < nb1; ++t) {
-    bf16x8 xb_cur[RT], xt_cur[RT][2];
-    float y_cur[RT];
+  {
+    const int rowg = 32 * ((nb0 < nb1 ? nb0 : 0) * RT + h) + r;
+    y_next = yv[rowg < p.N ? rowg : 0];
+  }
+  static_assert(RT == 2, "the head maps row tile q to lane half h = q");
+  bf16x8 xt_cur[RT][2];   // X^T of the pair whose first-layer weight gradient is still owed
+  constexpr int PPF = (NH & 1) ? 0 : 1;   // the dZ buffer the last hidden backward layer leaves dZ_1 in
+  // First-layer weight gradient of a finished pair.  It needs X^T from global memory and this wave's own dZ_1 columns
+  // (no other wave's data), so it is owed until the NEXT pair's first forward phase: there the X^T loads have had a
+  // whole phase to land and the four products fill the wait for the layer-1 epilogue.  (Done right after the last
+  // backward layer it cost ~1000 cycles per pair waiting for X^T, and the wave skew that left sat in the next barrier.)
+  auto first_layer_backward = [&]() {
+    bf16x8 bz[RT][2];   // all four reads first: read-then-use pairs pay the LDS latency once per product
 #pragma unroll
-    for (int q = 0; q < RT; ++q) {
-      xb_cur[q] = xb_next[q];
-      y_cur[q] = 0.0f;
-    }
-    // X of the next tile pair and X^T of this one are requested two phases before their use (not at the top:
-    // 24 registers held for a whole iteration spill)
+    for (int q = 0; q < RT; ++q)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) bz[q][s] = pim_tr_frag(tbw + LY::TILE + q * LY::TILE_BYTES + LY::DZ + PPF * LY::IMG + PIM_STRIDE * 16 * s);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < RT; ++q)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        dW1 = mfma_bf16(xt_cur[q][s], bz[q][s], dW1);
+        db[0] = bf16_colsum(bz[q][s], db[0]);
+      }
+  };
+  for (int t = nb0; t < nb1; ++t) {
+    bf16x8 xb_cur[RT];
+    const float y_cur = y_next;
+#pragma unroll
+    for (int q = 0; q < RT; ++q) xb_cur[q] = xb_next[q];
+    // X and the targets of the next tile pair, X^T of this one (its first-layer weight gradient is taken at the top of
+    // the next iteration)
     auto prefetch_x = [&]() {
+      const int tn = t + 1 < nb1 ? t + 1 : t;
 #pragma unroll
       for (int q = 0; q < RT; ++q) {
         const int row0 = 32 * (t * RT + q);
-        const int rown = 32 * ((t + 1 < nb1 ? t + 1 : t) * RT + q);
-        xb_next[q] = *reinterpret_cast<const bf16x8 *>(Xb + (size_t)(rown + r) * 16 + 8 * h);
+        xb_next[q] = *reinterpret_cast<const bf16x8 *>(Xb + (size_t)(32 * (tn * RT + q) + r) * 16 + 8 * h);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
           xt_cur[q][s] = *reinterpret_cast<const bf16x8 *>(Xt + (size_t)r * p.Npb + row0 + 16 * s + 8 * h);
       }
+      const int rowg = 32 * (tn * RT + h) + r;
+      y_next = yv[rowg < p.N ? rowg : 0];
     };
-    f32x16 acc[RT];
-    bf16x8 afp[8];   // weight fragments of the NEXT phase, read before the barrier that precedes it (they do not depend on it)
+    f32x16 acc[RT], zero16;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) zero16[j] = 0.0f;
+    // Operands that do not depend on the barrier in front of the phase that uses them are read BEFORE that barrier,
+    // among the previous phase's MFMAs, into the fragment registers those MFMAs have just consumed:
+    bf16x8 afp[8];           // weight fragments of the next phase
+    bf16x8 ahh[RT][2];       // head: this wave's own columns of H_NH, transposed (own data)
+    f32x2_t hmh[RT][4];      // head: this lane's own H_NH values (ReLU mask), kept from the forward epilogue
+    bf16x8 ah[RT][2][4];     // backward layer: H of the layer below, transposed (written in the forward pass)
+    bf16x8 bq[RT][2];        // backward layer: this wave's own dZ columns, transposed (own data)
+    f32x2_t hm[RT][4];       // backward layer: this lane's own H values of the layer below (ReLU mask)
+    uint32_t pk[RT][8];
+    auto relu_group = [&](int l, int q, int g) {   // H_l = relu(z): one 4-feature group of tile q into the image
+#ifdef MILE_LAB_NO_EPI
+      pk[q][2 * g] = __float_as_uint(acc[q][4 * g]); pk[q][2 * g + 1] = __float_as_uint(acc[q][4 * g + 1]);
+      return;
+#endif
+      store_group_relu(sb + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + l * LY::IMG + 16 * g, acc[q][4 * g], acc[q][4 * g + 1],
+                       acc[q][4 * g + 2], acc[q][4 * g + 3], pk[q][2 * g], pk[q][2 * g + 1]);
+    };
+    auto head_partial = [&](int q) {   // this wave's 32 of the 128 features: partial (mu, log sigma) per row of tile q
+      const u32x4_t p0 = {pk[q][0], pk[q][1], pk[q][2], pk[q][3]}, p1 = {pk[q][4], pk[q][5], pk[q][6], pk[q][7]};
+      f32x16 part = mfma_bf16(woF[0], __builtin_bit_cast(bf16x8, p0), zero16);
+      part = mfma_bf16(woF[1], __builtin_bit_cast(bf16x8, p1), part);
+      if (h == 0) {
+        const f32x2_t pv = {part[0], part[1]};
+        *reinterpret_cast<f32x2_t *>(lds + LY::PART + ((q * 4 + w) * 32 + r) * 8) = pv;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const u32x2_t m = {pk[q][2 * g], pk[q][2 * g + 1]};
+        hmh[q][g] = __builtin_bit_cast(f32x2_t, m);
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        ahh[q][s] = pim_tr_frag(tbw + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + (NH - 1) * LY::IMG + PIM_STRIDE * 16 * s);
+    };
+    auto masked_group = [&](int q, int g, int ppo, const f32x2_t m) {   // dZ = dH * (H > 0): one group of tile q
+#ifdef MILE_LAB_NO_EPI
+      if (acc[q][4 * g] == 123.0f) *reinterpret_cast<f32x2_t *>(sb) = m;
+      return;
+#endif
+      const f32x4_t v = {acc[q][4 * g], acc[q][4 * g + 1], acc[q][4 * g + 2], acc[q][4 * g + 3]};
+      store_group_masked(sb + LY::TILE + q * LY::TILE_BYTES + LY::DZ + ppo * LY::IMG + 16 * g, v, m);
+    };
     // ---- forward ---------------------------------------------------------------------------
+    // Tile 0's products first, then tile 1's with tile 0's epilogue (and the next phase's weight reads) in their gaps.
 #pragma unroll
     for (int l = 0; l < NH; ++l) {
       if (l == 0) {
         const f32x16 b0 = bias_tile(0);
 #pragma unroll
-        for (int q = 0; q < RT; ++q) {
-          acc[q] = mfma_bf16(w1frag, xb_cur[q], b0);
+        for (int q = 0; q < RT; ++q) acc[q] = mfma_bf16(w1frag, xb_cur[q], b0);
+        if (t > nb0) first_layer_backward();
+        __builtin_amdgcn_sched_barrier(0);
+        prefetch_x();   // into the registers just consumed
+        __builtin_amdgcn_sched_barrier(0);
+        tick(6);
+        if (NH > 1) {
+#pragma unroll
+          for (int s = 0; s < 8; ++s) afp[s] = pim_tr_frag(tbw + LY::WIMG + PIM_STRIDE * 16 * s);
         }
 #pragma unroll
-        for (int q = 0; q < RT; ++q) {   // targets: needed three phases from here
-          const int row0 = 32 * (t * RT + q);
-          y_cur[q] = yv[row0 + r < p.N ? row0 + r : 0];
+        for (int q = 0; q < RT; ++q) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) relu_group(0, q, g);
+          if (NH == 1) head_partial(q);
         }
       } else {
-        // all fragment reads of the phase are issued before the first MFMA: with one wave per SIMD nothing
-        // else hides the LDS latency, and read-then-use pairs would pay it once per MFMA
         bf16x8 bfr[RT][8];
         const f32x16 bl = bias_tile(l);
 #pragma unroll
-        for (int s = 0; s < 8; ++s)
+        for (int q = 0; q < RT; ++q)
 #pragma unroll
-          for (int q = 0; q < RT; ++q)
-            bfr[q][s] = *reinterpret_cast<const bf16x8 *>(rb + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + (l - 1) * LY::IMG + 32 * s);
+          for (int s = 0; s < 8; ++s)
+            bfr[q][s] = pim_row_read(rb + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + (l - 1) * LY::IMG + 32 * s);
         __builtin_amdgcn_sched_barrier(0);   // keep the reads above, the MFMAs below
 #pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-          for (int q = 0; q < RT; ++q) acc[q] = mfma_bf16(afp[s], bfr[q][s], s == 0 ? bl : acc[q]);
-      }
-#pragma unroll
-      for (int q = 0; q < RT; ++q) {
-        uint32_t pk[8];
-        store_tile_relu(sb + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + l * LY::IMG, acc[q], pk);
-        if (l == NH - 1) {   // head, this wave's 32 of the 128 features: partial (mu, log sigma) per row
-          f32x16 zero16, part;
-#pragma unroll
-          for (int j = 0; j < 16; ++j) zero16[j] = 0.0f;
-          const u32x4_t p0 = {pk[0], pk[1], pk[2], pk[3]}, p1 = {pk[4], pk[5], pk[6], pk[7]};
-          const bf16x8 b0 = __builtin_bit_cast(bf16x8, p0), b1 = __builtin_bit_cast(bf16x8, p1);
-          part = mfma_bf16(woF[0], b0, zero16);
-          part = mfma_bf16(woF[1], b1, part);
-          if (h == 0) {
-            const f32x2_t pv = {part[0], part[1]};
-            *reinterpret_cast<f32x2_t *>(lds + LY::PART + ((q * 4 + w) * 32 + r) * 8) = pv;
-          }
-        }
-      }
-      if (l + 1 < NH) {   // weights of layer l + 1 (image l), forward form
-#pragma unroll
-        for (int s = 0; s < 8; ++s) afp[s] = pim_tr_frag(tbw + LY::WIMG + l * LY::WBYTES + PIM_STRIDE * 16 * s);
+        for (int s = 0; s < 8; ++s) acc[0] = mfma_bf16(afp[s], bfr[0][s], s == 0 ? bl : acc[0]);
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          acc[1] = mfma_bf16(afp[s], bfr[1][s], s == 0 ? bl : acc[1]);
+          if (l + 1 < NH) afp[s] = pim_tr_frag(tbw + LY::WIMG + l * LY::WBYTES + PIM_STRIDE * 16 * s);                 // layer l + 1, forward form
+          else if (NH >= 2) afp[s] = pim_row_read(wb + LY::WIMG + (NH - 2) * LY::WBYTES + 32 * s);   // last hidden layer, backward form
+          if (s >= 2 && s < 6) relu_group(l, 0, s - 2);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (l == NH - 1) head_partial(0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) relu_group(l, 1, g);
+        if (l == NH - 1) head_partial(1);
       }
       lds_barrier();
       tick(l);
     }
-    // ---- head + backward through it: every wave sums the partials and evaluates the likelihood for its
-    // lanes' rows; d(out) feeds dH straight from registers, and, transposed through a private 128-byte
-    // buffer (no workgroup barrier), the head weight gradient
+    // ---- head + backward through it: lane (r, h) evaluates row r of tile q = h (one pass of the likelihood for both
+    // tiles); d(out) feeds dH straight from registers, and, transposed through a private 128-byte buffer (no workgroup
+    // barrier), the head weight gradient
     {
-      f32x16 zero16;
+      f32x2_t pr[4];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) zero16[j] = 0.0f;
-      f32x2_t pr[RT][4], hm[RT][4];
-      bf16x8 ah[RT][2];
-#pragma unroll
-      for (int q = 0; q < RT; ++q) {
-        constexpr int HOFF = LY::TILE + LY::HIMG + (NH - 1) * LY::IMG;
-        const int Hin = HOFF + q * LY::TILE_BYTES;
-#pragma unroll
-        for (int ww = 0; ww < 4; ++ww) pr[q][ww] = *reinterpret_cast<const f32x2_t *>(lds + LY::PART + ((q * 4 + ww) * 32 + r) * 8);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) hm[q][g] = *reinterpret_cast<const f32x2_t *>(sb + Hin + 16 * g);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) ah[q][s] = pim_tr_frag(tbw + Hin + PIM_STRIDE * 16 * s);
+      for (int ww = 0; ww < 4; ++ww) pr[ww] = *reinterpret_cast<const f32x2_t *>(lds + LY::PART + ((h * 4 + ww) * 32 + r) * 8);
+      if (NH == 1) {   // one hidden layer: no backward-form weights were read in the forward pass
       }
-      if (NH == 1) prefetch_x();
-      __builtin_amdgcn_sched_barrier(0);
+      if (NH >= 2) {   // operands of the first backward layer that are already final (forward-pass data)
 #pragma unroll
-      for (int q = 0; q < RT; ++q) {
-        const int row0 = 32 * (t * RT + q);
-        const float mu = ((pr[q][0][0] + pr[q][1][0]) + (pr[q][2][0] + pr[q][3][0])) + bo0;
-        const float sr = ((pr[q][0][1] + pr[q][1][1]) + (pr[q][2][1] + pr[q][3][1])) + bo1;
+        for (int q = 0; q < RT; ++q) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            hm[q][g] = *reinterpret_cast<const f32x2_t *>(sb + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + (NH - 2) * LY::IMG + 16 * g);
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+              ah[q][s][ib] = pim_tr_frag(tb + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + (NH - 2) * LY::IMG + PIM_STRIDE * 16 * s + 64 * ib);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const int rowg = 32 * (t * RT + h) + r;
+        const float mu = ((pr[0][0] + pr[1][0]) + (pr[2][0] + pr[3][0])) + bo0;
+        const float sr = ((pr[0][1] + pr[1][1]) + (pr[2][1] + pr[3][1])) + bo1;
         float dmu = 0.0f, dsg = 0.0f;
-        if (h == 0 && row0 + r < p.N) {
-          const float ll = row_loss_regr_fast(mu, sr, y_cur[q], dmu, dsg);
+        if (rowg < p.N) {
+          const float ll = row_loss_regr_fast(mu, sr, y_cur, dmu, dsg);
           ll_acc += ll;
         }
-        bf16x8 bdo;
+        const uint32_t dpk = cvt_pk_bf16(dmu, dsg);   // rows >= N carry zeros
+        // d(out) of tile q sits in lane half h = q.  woB holds the two output columns in the first two k-slots of BOTH
+        // halves, so tile q's product takes them from k-slots 8q, 8q + 1 with the other half's operand zeroed.
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bdo[j] = (bf16)0.0f;
-        bdo[0] = (bf16)dmu; bdo[1] = (bf16)dsg;          // lanes h = 1 and rows >= N carry zeros
-        acc[q] = mfma_bf16(woB, bdo, zero16);
-        char *dop = lds + LY::DOP + (w * RT + q) * 128;
-        if (h == 0) {
-          reinterpret_cast<bf16 *>(dop)[r] = bdo[0];
-          reinterpret_cast<bf16 *>(dop)[32 + r] = bdo[1];
+        for (int q = 0; q < RT; ++q) {
+          const u32x4_t bv = {h == q ? dpk : 0u, 0u, 0u, 0u};
+          acc[q] = mfma_bf16(woB, __builtin_bit_cast(bf16x8, bv), zero16);
         }
+        uint16_t *dop = reinterpret_cast<uint16_t *>(lds + LY::DOP + (w * RT + h) * 128);
+        dop[r] = (uint16_t)(dpk & 0xffffu);
+        dop[32 + r] = (uint16_t)(dpk >> 16);
       }
 #pragma unroll
       for (int q = 0; q < RT; ++q) {
@@ -354,108 +425,79 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           const char *src = r < 2 ? dop + r * 64 + 32 * s + 16 * h : lds + LY::ZERO;
-          const bf16x8 bq = *reinterpret_cast<const bf16x8 *>(src);
-          dWo = mfma_bf16(ah[q][s], bq, dWo);
-          dbo = bf16_colsum(bq, dbo);
+          const bf16x8 bo = *reinterpret_cast<const bf16x8 *>(src);
+          dWo = mfma_bf16(ahh[q][s], bo, dWo);
+          dbo = bf16_colsum(bo, dbo);
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4_t v = {acc[q][4 * g], acc[q][4 * g + 1], acc[q][4 * g + 2], acc[q][4 * g + 3]};
-          store_group_masked(sb + LY::TILE + q * LY::TILE_BYTES + LY::DZ + 16 * g, v, hm[q][g]);
-        }
+        for (int g = 0; g < 4; ++g) masked_group(q, g, 0, hmh[q][g]);
       }
-      if (NH >= 2) {   // weights of the last hidden layer, backward form
+      if (NH >= 2) {   // this wave's own dZ columns, just stored
 #pragma unroll
-        for (int s = 0; s < 8; ++s) afp[s] = *reinterpret_cast<const bf16x8 *>(wb + LY::WIMG + (NH - 2) * LY::WBYTES + 32 * s);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < RT; ++q)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) bq[q][s] = pim_tr_frag(tbw + LY::TILE + q * LY::TILE_BYTES + LY::DZ + PIM_STRIDE * 16 * s);
       }
     }
     lds_barrier();
     tick(3);
     // ---- backward: hidden layers NH .. 2 ------------------------------------------------------------
-    // Pinned order (sched_barrier fences): all dH operands are read first; the transposed dW operands
-    // are read between the dH MFMAs as those release registers; the dZ epilogue of the dH result runs
-    // between the dW MFMAs, which do not depend on it.
+    // Entered with afp (weights, backward form), ah, bq and hm of this layer in registers; only the dH operand (all
+    // waves' dZ columns) waits for the barrier.  Pinned order (sched_barrier fences): tile 0's dH products, tile 1's with
+    // tile 0's dZ epilogue and the next layer's weight reads in the gaps, then the dW products with tile 1's epilogue
+    // and the next layer's transposed H reads in the gaps.
     int pp = 0;
 #pragma unroll
     for (int l = NH - 1; l >= 1; --l) {   // dZ of layer l is in DZ[pp]; its input is H_l (image l-1)
-      f32x16 zero16;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) zero16[j] = 0.0f;
-      bf16x8 bfr[RT][8], bq[RT][2], ah[RT][2][4];
-      f32x2_t hm[RT][4];
-#pragma unroll
-      for (int s = 0; s < 8; ++s)
-#pragma unroll
-        for (int q = 0; q < RT; ++q)
-          bfr[q][s] = *reinterpret_cast<const bf16x8 *>(rb + LY::TILE + q * LY::TILE_BYTES + LY::DZ + pp * LY::IMG + 32 * s);
+      bf16x8 bfr[RT][8];
 #pragma unroll
       for (int q = 0; q < RT; ++q)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          hm[q][g] = *reinterpret_cast<const f32x2_t *>(sb + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + (l - 1) * LY::IMG + 16 * g);
+        for (int s = 0; s < 8; ++s)
+          bfr[q][s] = pim_row_read(rb + LY::TILE + q * LY::TILE_BYTES + LY::DZ + pp * LY::IMG + 32 * s);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) acc[0] = mfma_bf16(afp[s], bfr[0][s], s == 0 ? zero16 : acc[0]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-#pragma unroll
-        for (int q = 0; q < RT; ++q) acc[q] = mfma_bf16(afp[s], bfr[q][s], s == 0 ? zero16 : acc[q]);
-        {
-          const int q = (s * RT) / 8, sub = RT == 2 ? (s & 3) : (s >> 1);   // RT = 1: four steps carry reads
-          const int ts = LY::TILE + q * LY::TILE_BYTES;
-          const int dz = ts + LY::DZ + pp * LY::IMG, Hin = ts + LY::HIMG + (l - 1) * LY::IMG, R16 = PIM_STRIDE * 16;
-          if (RT == 2 || (s & 1) == 0) {
-            if (sub == 0) { bq[q][0] = pim_tr_frag(tbw + dz); ah[q][0][0] = pim_tr_frag(tb + Hin); ah[q][0][1] = pim_tr_frag(tb + Hin + 64); }
-            if (sub == 1) { ah[q][0][2] = pim_tr_frag(tb + Hin + 128); ah[q][0][3] = pim_tr_frag(tb + Hin + 192); bq[q][1] = pim_tr_frag(tbw + dz + R16); }
-            if (sub == 2) { ah[q][1][0] = pim_tr_frag(tb + Hin + R16); ah[q][1][1] = pim_tr_frag(tb + Hin + R16 + 64); }
-            if (sub == 3) { ah[q][1][2] = pim_tr_frag(tb + Hin + R16 + 128); ah[q][1][3] = pim_tr_frag(tb + Hin + R16 + 192); }
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (l == 1) {   // the dH operands are consumed: their registers take the global prefetch
-        prefetch_x();
+        acc[1] = mfma_bf16(afp[s], bfr[1][s], s == 0 ? zero16 : acc[1]);
+        if (l >= 2) afp[s] = pim_row_read(wb + LY::WIMG + (l - 2) * LY::WBYTES + 32 * s);
+        if (s >= 2 && s < 6) masked_group(0, s - 2, pp ^ 1, hm[0][s - 2]);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int q = 0; q < RT; ++q) {
-        char *dzo = sb + LY::TILE + q * LY::TILE_BYTES + LY::DZ + (pp ^ 1) * LY::IMG;
+      for (int q = 0; q < RT; ++q)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
           for (int ib = 0; ib < 4; ++ib) {
+            const int k = (q * 2 + s) * 4 + ib;
             dW[l - 1][ib] = mfma_bf16(ah[q][s][ib], bq[q][s], dW[l - 1][ib]);
-            if (ib & 1) {
-              const int g = 2 * s + (ib >> 1);
-              const f32x4_t v = {acc[q][4 * g], acc[q][4 * g + 1], acc[q][4 * g + 2], acc[q][4 * g + 3]};
-              store_group_masked(dzo + 16 * g, v, hm[q][g]);
-            }
+            if (l >= 2)
+              ah[q][s][ib] = pim_tr_frag(tb + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + (l - 2) * LY::IMG + PIM_STRIDE * 16 * s + 64 * ib);
+            if (k >= 2 && k < 6) masked_group(1, k - 2, pp ^ 1, hm[1][k - 2]);
+            if (ib == 3) db[l] = bf16_colsum(bq[q][s], db[l]);
+            __builtin_amdgcn_sched_barrier(0);
           }
-          db[l] = bf16_colsum(bq[q][s], db[l]);
-          __builtin_amdgcn_sched_barrier(0);
         }
-      }
       pp ^= 1;
-      if (l >= 2) {   // weights of the next layer down, backward form
+      if (l >= 2) {   // the next layer's mask and this wave's own dZ columns, just stored
 #pragma unroll
-        for (int s = 0; s < 8; ++s) afp[s] = *reinterpret_cast<const bf16x8 *>(wb + LY::WIMG + (l - 2) * LY::WBYTES + 32 * s);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < RT; ++q) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            hm[q][g] = *reinterpret_cast<const f32x2_t *>(sb + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + (l - 2) * LY::IMG + 16 * g);
+#pragma unroll
+          for (int s = 0; s < 2; ++s) bq[q][s] = pim_tr_frag(tbw + LY::TILE + q * LY::TILE_BYTES + LY::DZ + pp * LY::IMG + PIM_STRIDE * 16 * s);
+        }
       }
       lds_barrier();
       tick(3 + l);
     }
-    // ---- backward: first layer ------------------------------------------------------------------------
-#pragma unroll
-    for (int q = 0; q < RT; ++q) {
-      const char *dz = tbw + LY::TILE + q * LY::TILE_BYTES + LY::DZ + pp * LY::IMG;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const bf16x8 bq = pim_tr_frag(dz + PIM_STRIDE * 16 * s);
-        dW1 = mfma_bf16(xt_cur[q][s], bq, dW1);
-        db[0] = bf16_colsum(bq, db[0]);
-      }
-    }
-    tick(6);
+    static_assert(PPF == ((NH - 1) & 1), "dZ_1 buffer parity");
   }
+  if (nb1 > nb0) first_layer_backward();   // the last pair's
   if (TIMING && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && p.dbg_buf) {
 #pragma unroll
     for (int k = 0; k < 7; ++k) p.dbg_buf[k] = tph[k] / (unsigned)(nb1 - nb0 > 0 ? nb1 - nb0 : 1);
