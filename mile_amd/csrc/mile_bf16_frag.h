@@ -80,19 +80,23 @@ __device__ __forceinline__ bf16x8 pim_row_read(const char *a) {
 }
 __device__ __forceinline__ int pim_row(int i) { return (i & ~15) | ((i & 3) << 2) | (((i >> 3) & 1) << 1) | ((i >> 2) & 1); }
 __device__ __forceinline__ int pim_off(int row, int ch) { return PIM_STRIDE * pim_row(row) + 16 * ch; }
-// per-lane base of a transposed read (add PIM_STRIDE * row0 + 2 * col0, row0 a multiple of 16, col0 of 32)
+// per-lane base of a transposed read (add STRIDE * row0 + 2 * col0, row0 a multiple of 16, col0 of 32).  STRIDE: any row
+// pitch that is 16 mod 64 dwords per 4 rows, e.g. 272 bytes for 128-column images, 144 for 64-column ones.
+template <int STRIDE = PIM_STRIDE>
 __device__ __forceinline__ int pim_tr_base(int lane) {
+  static_assert((STRIDE % 16) == 0 && ((4 * STRIDE / 4) % 64) == 16, "padded image pitch");
   const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
-  return PIM_STRIDE * (4 * q + 2 * h) + 32 * g1 + 16 * (p >> 1) + 8 * (p & 1);
+  return STRIDE * (4 * q + 2 * h) + 32 * g1 + 16 * (p >> 1) + 8 * (p & 1);
 }
-// element j of lane (r, h) = image[row0 + 8h + j][col0 + r]; `a` = image + pim_tr_base(lane) + PIM_STRIDE * row0 + 2 * col0
+// element j of lane (r, h) = image[row0 + 8h + j][col0 + r]; `a` = image + pim_tr_base(lane) + STRIDE * row0 + 2 * col0
+template <int STRIDE = PIM_STRIDE>
 __device__ __forceinline__ bf16x8 pim_tr_frag(const char *a) {
 #ifdef MILE_LAB_NO_TR   // dev experiment (tools/r03/lab)
   const u32x4_lab v = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};   // one hoisted constant: no VALU added
   return __builtin_bit_cast(bf16x8, v);
 #endif
   const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, a));
-  const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, a + PIM_STRIDE));
+  const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MILE_LDS_PTR(bf16x4, a + STRIDE));
   return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 // two fp32 -> one packed bf16 pair (round to nearest even) in ONE v_cvt_pk_bf16_f32: the 2-vector conversion selects the

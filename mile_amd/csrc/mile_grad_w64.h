@@ -164,22 +164,32 @@ __device__ __forceinline__ void split3_natk(const f32x16 &T, bf16x8 (&fr)[3][2])
   natk_from_pk(pk, fr);
 }
 
-// The wave's private transposition buffer in the SPLIT variant: two swizzled [32 rows][128 columns] bf16 images
-// (mile_bf16_frag.h); term 0 of a 64-feature row lives in columns 0..63 of image 0, term 1 in columns 64..127 of image 0,
-// term 2 in columns 0..63 of image 1.  Stores tile kb (features 32kb..32kb+31) of all three terms: img[row j][feature].
-__device__ __forceinline__ void store_terms(char *si, int kb, const uint32_t (&pk)[3][8], int j, int h) {
+// The wave's private transposition buffer in the SPLIT variant: two padded bf16 images of the block's 32 rows
+// (mile_bf16_frag.h: every address = one per-lane base + an immediate).  Image 0, [32][128] at 272-byte rows: term 0 of a
+// 64-feature row in columns 0..63, term 1 in columns 64..127.  Image 1, [32][64] at 144-byte rows: term 2.
+#define W64_S2 144                                  // row pitch of image 1
+#define W64_SIMG0 (32 * PIM_STRIDE)                 // bytes of image 0 = offset of image 1
+#define W64_SIMG (W64_SIMG0 + 32 * W64_S2)          // both images
+#define W64_TIMG (64 * PIM_STRIDE)                  // one term image of a pair of weight layers: W^T[64 out][2 x 64 in], bytes
+struct W64ImgBases {   // per-lane bases into the wave's two term images
+  char *s01, *s2;              // stores: PIM_STRIDE * pim_row(j) + 8 h   /   W64_SIMG0 + W64_S2 * pim_row(j) + 8 h
+  const char *t01, *t2;        // transposed reads: pim_tr_base(lane)     /   W64_SIMG0 + pim_tr_base<W64_S2>(lane)
+};
+// Stores tile kb (features 32kb..32kb+31) of all three terms: img[row j][feature]
+__device__ __forceinline__ void store_terms(const W64ImgBases &ib, int kb, const uint32_t (&pk)[3][8]) {
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
       const u32x2 v = {pk[t][2 * g], pk[t][2 * g + 1]};
-      *reinterpret_cast<u32x2 *>(si + (t == 2 ? 8192 : 0) + img_off(j, (t == 1 ? 8 : 0) + 4 * kb + g) + 8 * h) = v;
+      *reinterpret_cast<u32x2 *>((t == 2 ? ib.s2 : ib.s01) + 16 * ((t == 1 ? 8 : 0) + 4 * kb + g)) = v;
     }
 }
 // transposed fragment of term t: element i of lane (r,h) = term t of img[row 16c + 8h + i][feature 32fb + r]
-__device__ __forceinline__ bf16x8 terms_tr_frag(const char *si, int t, int c, int fb, int lane) {
-  return tr_frag(si + (t == 2 ? 8192 : 0), 16 * c, (t == 1 ? 64 : 0) + 32 * fb, lane);
+__device__ __forceinline__ bf16x8 terms_tr_frag(const W64ImgBases &ib, int t, int c, int fb) {
+  if (t == 2) return pim_tr_frag<W64_S2>(ib.t2 + W64_S2 * 16 * c + 2 * (32 * fb));
+  return pim_tr_frag(ib.t01 + PIM_STRIDE * 16 * c + 2 * ((t == 1 ? 64 : 0) + 32 * fb));
 }
 
 // 8 fp32 values -> three bf16x8 terms (weight staging)
@@ -220,23 +230,24 @@ struct W64Layout {
   static constexpr int NW = (NH > 1 ? NH - 1 : 1);
   static constexpr int FP = 8 * FQ;
   static constexpr int WIMG = 0;                                  // [NH-1][64][68]
-  // SPLIT: instead, bf16 images W^T[out][in] of two layers side by side ([64][128] swizzled, mile_bf16_frag.h),
-  // one per split term: [NSET][3][64 x 256 bytes]
+  // SPLIT: instead, bf16 images W^T[out][in] of two layers side by side ([64][128], padded rows: mile_bf16_frag.h),
+  // one per split term: [NSET][3][W64_TIMG bytes]
   static constexpr int NSET = NH / 2;
   // The row-contracting dW products run on bf16 terms as well (SPLIT_DW; split_dw(l) selects it per layer).  With three
-  // hidden layers that only fits the register file because (a) the swizzled fragment addresses are re-derived per layer from
-  // an opaque copy of the lane index instead of living in ~30 hoisted registers, and (b) the first layer's activations wait
-  // in LDS between forward and backward (STASH: each wave's quarter of the tile-exchange buffer, idle in the main loop).
+  // hidden layers that only fits the register file because (a) every fragment address is one of four per-lane bases plus an
+  // immediate (padded images; the XOR-swizzled images of rounds 1-2 needed ~30 address registers, re-derived per layer),
+  // and (b) the first layer's activations wait in LDS between forward and backward (STASH: each wave's quarter of the
+  // tile-exchange buffer, idle in the main loop).
   static constexpr bool SPLIT_DW = SPLIT;
   __host__ __device__ static constexpr bool split_dw(int l) { return SPLIT; }
   static constexpr bool STASH = SPLIT && NH >= 3;
-  static constexpr int W1IMG = WIMG + (SPLIT ? NSET * 3 * 4096 : (NH - 1) * 64 * W64_RS);   // [FP][68]
+  static constexpr int W1IMG = WIMG + (SPLIT ? NSET * 3 * (W64_TIMG / 4) : (NH - 1) * 64 * W64_RS);   // [FP][68]
   static constexpr int BIAS = W1IMG + FP * W64_RS;                // [NH][64]
   static constexpr int WO = BIAS + NH * 64;                       // [2][64]
   static constexpr int BO = WO + 128;                             // [4]
   static constexpr int WAVE0 = BO + 4;
-  static constexpr int IMG = 0;                                   // per wave: [32][68]; SPLIT_DW: aliased by two bf16 images, 16 KB
-  static constexpr int XT = IMG + (SPLIT_DW ? 4096 : 32 * W64_RS);   // [32][FP]
+  static constexpr int IMG = 0;                                   // per wave: [32][68]; SPLIT_DW: aliased by two bf16 images, 13 KB
+  static constexpr int XT = IMG + (SPLIT_DW ? W64_SIMG / 4 : 32 * W64_RS);   // [32][FP]
   static constexpr int DOUT = XT + 32 * FP;                       // [32][2]
   static constexpr int WAVE_SZ = DOUT + 64;
   static constexpr int XB = WAVE0 + 4 * WAVE_SZ;                  // [2 pairs][2][2][16][64] tile exchange (COOP)
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p, const t
   long long *stamps = p.dbg_buf + ((size_t)e * p.S + s) * 16;
   if (stamp) stamps[0] = wall_clock64();
   // ---- stage this particle's weights in LDS --------------------------------------
-  char *BIMG = reinterpret_cast<char *>(WIMG);   // SPLIT: term t of image set s at BIMG + (3 s + t) * 16384
+  char *BIMG = reinterpret_cast<char *>(WIMG);   // SPLIT: term t of image set s at BIMG + (3 s + t) * W64_TIMG
   if (!(p.dbg & 2))
   for (int l = 1; l < NH; ++l) {
     const float *W = th + sp.w_off[l];
@@ -307,7 +318,7 @@ __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p, const t
         split3_vec(x, tv);
 #pragma unroll
         for (int tt = 0; tt < 3; ++tt)
-          *reinterpret_cast<bf16x8 *>(BIMG + (3 * ((l - 1) >> 1) + tt) * 16384 + img_off(o, 8 * ((l - 1) & 1) + ic)) = tv[tt];
+          *reinterpret_cast<bf16x8 *>(BIMG + (3 * ((l - 1) >> 1) + tt) * W64_TIMG + pim_off(o, 8 * ((l - 1) & 1) + ic)) = tv[tt];
       }
     } else {
       for (int idx = tid; idx < 4096; idx += 256) WIMG[(l - 1) * 64 * W64_RS + (idx >> 6) * W64_RS + (idx & 63)] = W[idx];
@@ -376,6 +387,14 @@ __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p, const t
       for (int r = 0; r < 16; ++r) T[0][r] = xb[r * 64 + lane];
     }
   };
+  // SPLIT: the six per-lane LDS bases of the bf16 images (everything else in an address is an immediate)
+  const char *wrb = BIMG + PIM_STRIDE * pim_row(j) + 16 * h;                          // weight rows (forward): + term + 32 ob rows + chunk
+  const char *wtb = BIMG + pim_tr_base(lane);                                         // weights transposed (dH)
+  W64ImgBases imb;                                                                    // this wave's term images
+  imb.s01 = reinterpret_cast<char *>(img) + PIM_STRIDE * pim_row(j) + 8 * h;
+  imb.s2 = reinterpret_cast<char *>(img) + W64_SIMG0 + W64_S2 * pim_row(j) + 8 * h;
+  imb.t01 = reinterpret_cast<const char *>(img) + pim_tr_base(lane);
+  imb.t2 = reinterpret_cast<const char *>(img) + W64_SIMG0 + pim_tr_base<W64_S2>(lane);
   const int nblk = b1 - b0, nfull = nblk >> 2, rem = nblk & 3;
   f32x4 xv_pre[FQ];   // X tile of the next full round, requested one block ahead
 #pragma unroll
