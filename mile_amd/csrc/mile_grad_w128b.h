@@ -12,26 +12,35 @@
 // same 32-row tile; wave w owns feature block w (32 of the 128 features) of every hidden layer:
 // its slice of the activations, of dZ and -- the reason for the split -- its 128 x 32 column slice
 // of every weight gradient, which lives in accumulator registers for the whole kernel (a full
-// 128 x 128 fp32 gradient per layer does not fit one wave).  Tiles are exchanged through swizzled
-// [32][128] bf16 LDS images (mile_bf16_frag.h) that serve both the row reads (forward / dH) and the
-// transposed reads (dW contracts over rows) without a second copy; the bf16 weight images serve
-// forward (transposed read) and backward (row read) the same way.
+// 128 x 128 fp32 gradient per layer does not fit one wave).  Tiles are exchanged through padded
+// [32][128] bf16 LDS images (mile_bf16_frag.h: 272-byte rows, 16-row groups permuted) that serve both the
+// row reads (forward / dH) and the transposed reads (dW contracts over rows) without a second copy and
+// without bank conflicts, every address one of five per-lane bases plus an immediate; the bf16 weight
+// images serve forward (transposed read) and backward (row read) the same way.
 //
-// One wave per SIMD leaves nobody to hide a wave's own LDS latency, MFMA drain and barrier waits, so
+// One wave per SIMD leaves nobody to hide a wave's own LDS latency, MFMA drain and barrier waits.  The matrix
+// products themselves are hidden already (removing every MFMA buys 3 %: profiles/r03/18_w128b_lab_ablation.md);
+// what the kernel is made of is operand traffic, epilogue VALU and barrier skew, so
 //  * each iteration walks RT = 2 row tiles between the same 2*NH barriers; they share every weight
 //    fragment, and the barrier cost per tile halves;
-//  * all fragment reads of a phase are issued before its first MFMA (sched_barrier fences: left alone,
-//    the compiler sinks every read next to its use and pays the LDS latency once per MFMA); in the
-//    backward layers the transposed dW operands are read between the dH MFMAs and the dZ epilogue
-//    runs between the dW MFMAs;
-//  * epilogues are packed: the bias tile is the first MFMA's C operand, ReLU and its derivative are
-//    16-bit integer ops on bf16 bit patterns, bias gradients are v_dot2c_f32_bf16 column sums of the
-//    transposed dZ fragments the dW products read anyway;
+//  * a phase issues only the reads that wait for its barrier (tile 0's dH / forward operand) before its first
+//    MFMA, tile 1's in the gaps of tile 0's products; everything that does NOT depend on the barrier -- the
+//    weights, the transposed H of the layer below, this wave's own dZ columns and ReLU masks -- is read in the
+//    gaps of the PREVIOUS phase's products, into the fragment registers those products have just consumed
+//    (sched_barrier fences pin the order: left alone, the compiler sinks every read next to its use and pays
+//    the LDS latency once per MFMA);
+//  * tile 0's epilogue runs in the gaps of tile 1's products, tile 1's in the gaps of the dW products;
+//  * epilogues are packed: the bias tile is the first MFMA's C operand, one v_cvt_pk_bf16_f32 per pair, ReLU
+//    and its derivative are 16-bit integer ops on bf16 bit patterns, bias gradients are v_dot2c_f32_bf16
+//    column sums of the transposed dZ fragments the dW products read anyway;
 //  * the head never touches a full H: each wave multiplies its own H tile straight from the
 //    accumulator registers into partial (mu, log sigma), the partials meet in LDS behind the barrier
-//    the forward pass needs anyway, and d(out) reaches dH from registers and the head-weight product
-//    through a private 128-byte transposed buffer.
-// Measured history and counters: profiles/r01/07_b3_bf16_notes.md.
+//    the forward pass needs anyway; lane half h evaluates the likelihood of tile h (one pass for both tiles),
+//    d(out) reaches dH from registers and the head-weight product through a private 128-byte transposed buffer;
+//  * global operands (X, X^T, targets) are requested a whole tile pair ahead, and the first-layer weight
+//    gradient of a pair is taken at the top of the next pair's first phase.
+// Measured history and counters: profiles/r01/07_b3_bf16_notes.md (round 1), profiles/r03/16_* (round 2 kernel),
+// profiles/r03/17_b3_*, 18_w128b_lab_ablation.md (this form: 5.78 -> 4.9 ms at B3).
 #pragma once
 #include "mile_bf16_frag.h"
 #include "mile_device.h"
@@ -223,34 +232,52 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
   const int nb0 = (int)((long long)sidx * NBS / p.S), nb1 = (int)((long long)(sidx + 1) * NBS / p.S);
 
   // Global operands are fetched a whole tile pair ahead of their use, right after the registers' previous contents are
-  // consumed at the top of the loop: with one wave per SIMD nothing hides a global load, and these took > 2000 cycles to
-  // land even from L2 (measured: requested one phase ahead, the top of the loop still waited ~1000 cycles per pair).
-  // lane (r, h) holds the target of row r of tile h.
-  bf16x8 xb_next[RT];
-  float y_next;
-#pragma unroll
-  for (int q = 0; q < RT; ++q) {
-    const int rowc = 32 * (nb0 < nb1 ? nb0 * RT + q : 0);
-    xb_next[q] = *reinterpret_cast<const bf16x8 *>(Xb + (size_t)(rowc + r) * 16 + 8 * h);
-  }
-  {
-    const int rowg = 32 * ((nb0 < nb1 ? nb0 : 0) * RT + h) + r;
-    y_next = yv[rowg < p.N ? rowg : 0];
-  }
+  // consumed: with one wave per SIMD nothing hides a global load, and these took > 2000 cycles to land even from L2
+  // (measured: requested one phase ahead, the consumer still waited ~1000 cycles per pair).
   static_assert(RT == 2, "the head maps row tile q to lane half h = q");
-  bf16x8 xt_cur[RT][2];   // X^T of the pair whose first-layer weight gradient is still owed
+  constexpr bool MERGE = NH >= 2;   // the first layer of the NEXT pair runs inside this pair's last backward phase
   constexpr int PPF = (NH & 1) ? 0 : 1;   // the dZ buffer the last hidden backward layer leaves dZ_1 in
-  // First-layer weight gradient of a finished pair.  It needs X^T from global memory and this wave's own dZ_1 columns
-  // (no other wave's data), so it is owed until the NEXT pair's first forward phase: there the X^T loads have had a
-  // whole phase to land and the four products fill the wait for the layer-1 epilogue.  (Done right after the last
-  // backward layer it cost ~1000 cycles per pair waiting for X^T, and the wave skew that left sat in the next barrier.)
-  auto first_layer_backward = [&]() {
-    bf16x8 bz[RT][2];   // all four reads first: read-then-use pairs pay the LDS latency once per product
+  static_assert(PPF == ((NH - 1) & 1), "dZ_1 buffer parity");
+  const int t_end = nb1 - 1;
+  bf16x8 xb_next[RT];      // X of the pair whose first layer comes next
+  bf16x8 xt_cur[RT][2];    // X^T and ...
+  bf16x8 bz[RT][2];        // ... this wave's own dZ_1 columns (transposed) of the pair whose first-layer weight gradient is owed
+  float y_next;            // lane (r, h): target of row r of tile h
+  auto load_xb = [&](int tt) {
+#pragma unroll
+    for (int q = 0; q < RT; ++q) xb_next[q] = *reinterpret_cast<const bf16x8 *>(Xb + (size_t)(32 * (tt * RT + q) + r) * 16 + 8 * h);
+  };
+  auto load_xt = [&](int tt) {
+#pragma unroll
+    for (int q = 0; q < RT; ++q)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        xt_cur[q][s] = *reinterpret_cast<const bf16x8 *>(Xt + (size_t)r * p.Npb + 32 * (tt * RT + q) + 16 * s + 8 * h);
+  };
+  auto load_y = [&](int tt) {
+    const int rowg = 32 * (tt * RT + h) + r;
+    y_next = yv[rowg < p.N ? rowg : 0];
+  };
+  {
+    const u32x4_t z4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int q = 0; q < RT; ++q)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) { xt_cur[q][s] = __builtin_bit_cast(bf16x8, z4); bz[q][s] = __builtin_bit_cast(bf16x8, z4); }
+  }
+  load_xb(nb0 < nb1 ? nb0 : 0);
+  load_y(nb0 < nb1 ? nb0 : 0);
+  // First-layer weight gradient of a finished pair: X^T from global memory times this wave's own dZ_1 columns (no other
+  // wave's data).  Owed until the next pair: the dZ_1 fragments are read at the end of the last backward phase (before its
+  // barrier), the four products run right behind that barrier while the next phase's operands are in flight -- done where
+  // the data is produced it cost ~1000 cycles per pair waiting for X^T and the LDS round trip.
+  auto dz1_reads = [&]() {
 #pragma unroll
     for (int q = 0; q < RT; ++q)
 #pragma unroll
       for (int s = 0; s < 2; ++s) bz[q][s] = pim_tr_frag(tbw + LY::TILE + q * LY::TILE_BYTES + LY::DZ + PPF * LY::IMG + PIM_STRIDE * 16 * s);
-    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto first_layer_products = [&]() {
 #pragma unroll
     for (int q = 0; q < RT; ++q)
 #pragma unroll
@@ -259,117 +286,134 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
         db[0] = bf16_colsum(bz[q][s], db[0]);
       }
   };
+  f32x16 acc[RT], accf[RT], zero16;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) zero16[j] = 0.0f;
+  // Operands that do not depend on the barrier in front of the phase that uses them are read BEFORE that barrier,
+  // among the previous phase's MFMAs, into the fragment registers those MFMAs have just consumed:
+  bf16x8 afp[8];           // weight fragments of the next phase
+  bf16x8 ahh[RT][2];       // head: this wave's own columns of H_NH, transposed (own data)
+  f32x2_t hmh[RT][4];      // head: this lane's own H_NH values (ReLU mask), kept from the forward epilogue
+  bf16x8 ah[RT][2][4];     // backward layer: H of the layer below, transposed (written in the forward pass)
+  bf16x8 bq[RT][2];        // backward layer: this wave's own dZ columns, transposed (own data)
+  f32x2_t hm[RT][4];       // backward layer: this lane's own H values of the layer below (ReLU mask)
+  uint32_t pk[RT][8];
+  auto relu_group = [&](const f32x16 (&z)[RT], int l, int q, int g) {   // H_l = relu(z): one 4-feature group of tile q into the image
+#ifdef MILE_LAB_NO_EPI
+    pk[q][2 * g] = __float_as_uint(z[q][4 * g]); pk[q][2 * g + 1] = __float_as_uint(z[q][4 * g + 1]);
+    return;
+#endif
+    store_group_relu(sb + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + l * LY::IMG + 16 * g, z[q][4 * g], z[q][4 * g + 1],
+                     z[q][4 * g + 2], z[q][4 * g + 3], pk[q][2 * g], pk[q][2 * g + 1]);
+  };
+  auto head_partial = [&](int q) {   // this wave's 32 of the 128 features: partial (mu, log sigma) per row of tile q
+    const u32x4_t p0 = {pk[q][0], pk[q][1], pk[q][2], pk[q][3]}, p1 = {pk[q][4], pk[q][5], pk[q][6], pk[q][7]};
+    f32x16 part = mfma_bf16(woF[0], __builtin_bit_cast(bf16x8, p0), zero16);
+    part = mfma_bf16(woF[1], __builtin_bit_cast(bf16x8, p1), part);
+    if (h == 0) {
+      const f32x2_t pv = {part[0], part[1]};
+      *reinterpret_cast<f32x2_t *>(lds + LY::PART + ((q * 4 + w) * 32 + r) * 8) = pv;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const u32x2_t m = {pk[q][2 * g], pk[q][2 * g + 1]};
+      hmh[q][g] = __builtin_bit_cast(f32x2_t, m);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      ahh[q][s] = pim_tr_frag(tbw + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + (NH - 1) * LY::IMG + PIM_STRIDE * 16 * s);
+  };
+  auto dout_frag = [&](int q, int s) {   // d(out) of tile q, rows 16 s .., transposed: B[k = row][n = output] from the private buffer
+    const char *dop = lds + LY::DOP + (w * RT + q) * 128;
+    const char *src = r < 2 ? dop + r * 64 + 32 * s + 16 * h : lds + LY::ZERO;
+    return *reinterpret_cast<const bf16x8 *>(src);
+  };
+  auto masked_group = [&](int q, int g, int ppo, const f32x2_t m) {   // dZ = dH * (H > 0): one group of tile q
+#ifdef MILE_LAB_NO_EPI
+    if (acc[q][4 * g] == 123.0f) *reinterpret_cast<f32x2_t *>(sb) = m;
+    return;
+#endif
+    const f32x4_t v = {acc[q][4 * g], acc[q][4 * g + 1], acc[q][4 * g + 2], acc[q][4 * g + 3]};
+    store_group_masked(sb + LY::TILE + q * LY::TILE_BYTES + LY::DZ + ppo * LY::IMG + 16 * g, v, m);
+  };
+  if (MERGE && nb0 < nb1) {   // H_1 of the first pair; every later pair's is formed inside its predecessor's last backward phase
+    const f32x16 b0 = bias_tile(0);
+#pragma unroll
+    for (int q = 0; q < RT; ++q) accf[q] = mfma_bf16(w1frag, xb_next[q], b0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) afp[s] = pim_tr_frag(tbw + LY::WIMG + PIM_STRIDE * 16 * s);
+    load_xb(nb0 < t_end ? nb0 + 1 : t_end);
+#pragma unroll
+    for (int q = 0; q < RT; ++q)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) relu_group(accf, 0, q, g);
+    lds_barrier();
+  }
   for (int t = nb0; t < nb1; ++t) {
-    bf16x8 xb_cur[RT];
     const float y_cur = y_next;
-#pragma unroll
-    for (int q = 0; q < RT; ++q) xb_cur[q] = xb_next[q];
-    // X and the targets of the next tile pair, X^T of this one (its first-layer weight gradient is taken at the top of
-    // the next iteration)
-    auto prefetch_x = [&]() {
-      const int tn = t + 1 < nb1 ? t + 1 : t;
-#pragma unroll
-      for (int q = 0; q < RT; ++q) {
-        const int row0 = 32 * (t * RT + q);
-        xb_next[q] = *reinterpret_cast<const bf16x8 *>(Xb + (size_t)(32 * (tn * RT + q) + r) * 16 + 8 * h);
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-          xt_cur[q][s] = *reinterpret_cast<const bf16x8 *>(Xt + (size_t)r * p.Npb + row0 + 16 * s + 8 * h);
-      }
-      const int rowg = 32 * (tn * RT + h) + r;
-      y_next = yv[rowg < p.N ? rowg : 0];
-    };
-    f32x16 acc[RT], zero16;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) zero16[j] = 0.0f;
-    // Operands that do not depend on the barrier in front of the phase that uses them are read BEFORE that barrier,
-    // among the previous phase's MFMAs, into the fragment registers those MFMAs have just consumed:
-    bf16x8 afp[8];           // weight fragments of the next phase
-    bf16x8 ahh[RT][2];       // head: this wave's own columns of H_NH, transposed (own data)
-    f32x2_t hmh[RT][4];      // head: this lane's own H_NH values (ReLU mask), kept from the forward epilogue
-    bf16x8 ah[RT][2][4];     // backward layer: H of the layer below, transposed (written in the forward pass)
-    bf16x8 bq[RT][2];        // backward layer: this wave's own dZ columns, transposed (own data)
-    f32x2_t hm[RT][4];       // backward layer: this lane's own H values of the layer below (ReLU mask)
-    uint32_t pk[RT][8];
-    auto relu_group = [&](int l, int q, int g) {   // H_l = relu(z): one 4-feature group of tile q into the image
-#ifdef MILE_LAB_NO_EPI
-      pk[q][2 * g] = __float_as_uint(acc[q][4 * g]); pk[q][2 * g + 1] = __float_as_uint(acc[q][4 * g + 1]);
-      return;
-#endif
-      store_group_relu(sb + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + l * LY::IMG + 16 * g, acc[q][4 * g], acc[q][4 * g + 1],
-                       acc[q][4 * g + 2], acc[q][4 * g + 3], pk[q][2 * g], pk[q][2 * g + 1]);
-    };
-    auto head_partial = [&](int q) {   // this wave's 32 of the 128 features: partial (mu, log sigma) per row of tile q
-      const u32x4_t p0 = {pk[q][0], pk[q][1], pk[q][2], pk[q][3]}, p1 = {pk[q][4], pk[q][5], pk[q][6], pk[q][7]};
-      f32x16 part = mfma_bf16(woF[0], __builtin_bit_cast(bf16x8, p0), zero16);
-      part = mfma_bf16(woF[1], __builtin_bit_cast(bf16x8, p1), part);
-      if (h == 0) {
-        const f32x2_t pv = {part[0], part[1]};
-        *reinterpret_cast<f32x2_t *>(lds + LY::PART + ((q * 4 + w) * 32 + r) * 8) = pv;
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const u32x2_t m = {pk[q][2 * g], pk[q][2 * g + 1]};
-        hmh[q][g] = __builtin_bit_cast(f32x2_t, m);
-      }
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-        ahh[q][s] = pim_tr_frag(tbw + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + (NH - 1) * LY::IMG + PIM_STRIDE * 16 * s);
-    };
-    auto masked_group = [&](int q, int g, int ppo, const f32x2_t m) {   // dZ = dH * (H > 0): one group of tile q
-#ifdef MILE_LAB_NO_EPI
-      if (acc[q][4 * g] == 123.0f) *reinterpret_cast<f32x2_t *>(sb) = m;
-      return;
-#endif
-      const f32x4_t v = {acc[q][4 * g], acc[q][4 * g + 1], acc[q][4 * g + 2], acc[q][4 * g + 3]};
-      store_group_masked(sb + LY::TILE + q * LY::TILE_BYTES + LY::DZ + ppo * LY::IMG + 16 * g, v, m);
-    };
+    const int tn = t < t_end ? t + 1 : t_end, tnn = t + 2 <= t_end ? t + 2 : t_end;
     // ---- forward ---------------------------------------------------------------------------
     // Tile 0's products first, then tile 1's with tile 0's epilogue (and the next phase's weight reads) in their gaps.
 #pragma unroll
     for (int l = 0; l < NH; ++l) {
       if (l == 0) {
+        if (MERGE) continue;   // done a pair ago
+        // one hidden layer: the first layer is the whole forward pass
         const f32x16 b0 = bias_tile(0);
 #pragma unroll
-        for (int q = 0; q < RT; ++q) acc[q] = mfma_bf16(w1frag, xb_cur[q], b0);
-        if (t > nb0) first_layer_backward();
+        for (int q = 0; q < RT; ++q) acc[q] = mfma_bf16(w1frag, xb_next[q], b0);
+        if (t > nb0) {
+          dz1_reads();
+          __builtin_amdgcn_sched_barrier(0);
+          first_layer_products();
+        }
         __builtin_amdgcn_sched_barrier(0);
-        prefetch_x();   // into the registers just consumed
+        load_xb(tn);   // into the registers just consumed
+        load_xt(t);
         __builtin_amdgcn_sched_barrier(0);
         tick(6);
-        if (NH > 1) {
-#pragma unroll
-          for (int s = 0; s < 8; ++s) afp[s] = pim_tr_frag(tbw + LY::WIMG + PIM_STRIDE * 16 * s);
-        }
 #pragma unroll
         for (int q = 0; q < RT; ++q) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) relu_group(0, q, g);
-          if (NH == 1) head_partial(q);
+          for (int g = 0; g < 4; ++g) relu_group(acc, 0, q, g);
+          head_partial(q);
         }
       } else {
         bf16x8 bfr[RT][8];
         const f32x16 bl = bias_tile(l);
 #pragma unroll
-        for (int q = 0; q < RT; ++q)
-#pragma unroll
-          for (int s = 0; s < 8; ++s)
-            bfr[q][s] = pim_row_read(rb + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + (l - 1) * LY::IMG + 32 * s);
+        for (int s = 0; s < 8; ++s) bfr[0][s] = pim_row_read(rb + LY::TILE + LY::HIMG + (l - 1) * LY::IMG + 32 * s);
         __builtin_amdgcn_sched_barrier(0);   // keep the reads above, the MFMAs below
+        if (MERGE && l == 1) {   // the previous pair's first-layer weight gradient (operands in registers) covers the wait
+          first_layer_products();
+          __builtin_amdgcn_sched_barrier(0);
+          load_xt(t);            // into the registers just consumed
+          __builtin_amdgcn_sched_barrier(0);
+          tick(6);
+        }
 #pragma unroll
-        for (int s = 0; s < 8; ++s) acc[0] = mfma_bf16(afp[s], bfr[0][s], s == 0 ? bl : acc[0]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < 8; ++s) {   // tile 1's operands are requested in the gaps of tile 0's products
+          acc[0] = mfma_bf16(afp[s], bfr[0][s], s == 0 ? bl : acc[0]);
+          bfr[1][s] = pim_row_read(rb + LY::TILE + LY::TILE_BYTES + LY::HIMG + (l - 1) * LY::IMG + 32 * s);
+          if (NH >= 2 && l == NH - 1) {   // operands of the first backward layer that are already final: H_{NH-1}, transposed, tile 0
+            ah[0][s >> 2][s & 3] = pim_tr_frag(tb + LY::TILE + LY::HIMG + (NH - 2) * LY::IMG + PIM_STRIDE * 16 * (s >> 2) + 64 * (s & 3));
+            hm[s >> 2][s & 3] = *reinterpret_cast<const f32x2_t *>(sb + LY::TILE + (s >> 2) * LY::TILE_BYTES + LY::HIMG + (NH - 2) * LY::IMG + 16 * (s & 3));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
           acc[1] = mfma_bf16(afp[s], bfr[1][s], s == 0 ? bl : acc[1]);
           if (l + 1 < NH) afp[s] = pim_tr_frag(tbw + LY::WIMG + l * LY::WBYTES + PIM_STRIDE * 16 * s);                 // layer l + 1, forward form
           else if (NH >= 2) afp[s] = pim_row_read(wb + LY::WIMG + (NH - 2) * LY::WBYTES + 32 * s);   // last hidden layer, backward form
-          if (s >= 2 && s < 6) relu_group(l, 0, s - 2);
+          if (s >= 2 && s < 6) relu_group(acc, l, 0, s - 2);
+          if (NH >= 2 && l == NH - 1)   // ... tile 1
+            ah[1][s >> 2][s & 3] = pim_tr_frag(tb + LY::TILE + LY::TILE_BYTES + LY::HIMG + (NH - 2) * LY::IMG + PIM_STRIDE * 16 * (s >> 2) + 64 * (s & 3));
           __builtin_amdgcn_sched_barrier(0);
         }
         if (l == NH - 1) head_partial(0);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) relu_group(l, 1, g);
+        for (int g = 0; g < 4; ++g) relu_group(acc, l, 1, g);
         if (l == NH - 1) head_partial(1);
       }
       lds_barrier();
@@ -382,21 +426,6 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
       f32x2_t pr[4];
 #pragma unroll
       for (int ww = 0; ww < 4; ++ww) pr[ww] = *reinterpret_cast<const f32x2_t *>(lds + LY::PART + ((h * 4 + ww) * 32 + r) * 8);
-      if (NH == 1) {   // one hidden layer: no backward-form weights were read in the forward pass
-      }
-      if (NH >= 2) {   // operands of the first backward layer that are already final (forward-pass data)
-#pragma unroll
-        for (int q = 0; q < RT; ++q) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            hm[q][g] = *reinterpret_cast<const f32x2_t *>(sb + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + (NH - 2) * LY::IMG + 16 * g);
-#pragma unroll
-          for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int ib = 0; ib < 4; ++ib)
-              ah[q][s][ib] = pim_tr_frag(tb + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + (NH - 2) * LY::IMG + PIM_STRIDE * 16 * s + 64 * ib);
-        }
-      }
       __builtin_amdgcn_sched_barrier(0);
       {
         const int rowg = 32 * (t * RT + h) + r;
@@ -407,6 +436,7 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
           const float ll = row_loss_regr_fast(mu, sr, y_cur, dmu, dsg);
           ll_acc += ll;
         }
+        load_y(tn);   // the next pair's targets, a pair ahead
         const uint32_t dpk = cvt_pk_bf16(dmu, dsg);   // rows >= N carry zeros
         // d(out) of tile q sits in lane half h = q.  woB holds the two output columns in the first two k-slots of BOTH
         // halves, so tile q's product takes them from k-slots 8q, 8q + 1 with the other half's operand zeroed.
@@ -421,11 +451,9 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
       }
 #pragma unroll
       for (int q = 0; q < RT; ++q) {
-        const char *dop = lds + LY::DOP + (w * RT + q) * 128;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          const char *src = r < 2 ? dop + r * 64 + 32 * s + 16 * h : lds + LY::ZERO;
-          const bf16x8 bo = *reinterpret_cast<const bf16x8 *>(src);
+          const bf16x8 bo = dout_frag(q, s);
           dWo = mfma_bf16(ahh[q][s], bo, dWo);
           dbo = bf16_colsum(bo, dbo);
         }
@@ -445,25 +473,30 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
     // Entered with afp (weights, backward form), ah, bq and hm of this layer in registers; only the dH operand (all
     // waves' dZ columns) waits for the barrier.  Pinned order (sched_barrier fences): tile 0's dH products, tile 1's with
     // tile 0's dZ epilogue and the next layer's weight reads in the gaps, then the dW products with tile 1's epilogue
-    // and the next layer's transposed H reads in the gaps.
+    // and the next layer's transposed H reads in the gaps.  The LAST backward phase has no next layer to read for: its
+    // dW gaps carry the whole first layer of the NEXT tile pair instead (two products from X in registers, the ReLU
+    // epilogue into the H_1 images -- dead since their transposed reads a phase ago -- and the second layer's forward
+    // weight fragments), which removes one phase and one barrier per pair.
     int pp = 0;
 #pragma unroll
     for (int l = NH - 1; l >= 1; --l) {   // dZ of layer l is in DZ[pp]; its input is H_l (image l-1)
       bf16x8 bfr[RT][8];
+      f32x16 b0f;
 #pragma unroll
-      for (int q = 0; q < RT; ++q)
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-          bfr[q][s] = pim_row_read(rb + LY::TILE + q * LY::TILE_BYTES + LY::DZ + pp * LY::IMG + 32 * s);
+      for (int s = 0; s < 8; ++s) bfr[0][s] = pim_row_read(rb + LY::TILE + LY::DZ + pp * LY::IMG + 32 * s);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < 8; ++s) acc[0] = mfma_bf16(afp[s], bfr[0][s], s == 0 ? zero16 : acc[0]);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int s = 0; s < 8; ++s) {
+        acc[0] = mfma_bf16(afp[s], bfr[0][s], s == 0 ? zero16 : acc[0]);
+        bfr[1][s] = pim_row_read(rb + LY::TILE + LY::TILE_BYTES + LY::DZ + pp * LY::IMG + 32 * s);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         acc[1] = mfma_bf16(afp[s], bfr[1][s], s == 0 ? zero16 : acc[1]);
         if (l >= 2) afp[s] = pim_row_read(wb + LY::WIMG + (l - 2) * LY::WBYTES + 32 * s);
         if (s >= 2 && s < 6) masked_group(0, s - 2, pp ^ 1, hm[0][s - 2]);
+        if (l == 1 && s == 7) b0f = bias_tile(0);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
@@ -478,6 +511,12 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
               ah[q][s][ib] = pim_tr_frag(tb + LY::TILE + q * LY::TILE_BYTES + LY::HIMG + (l - 2) * LY::IMG + PIM_STRIDE * 16 * s + 64 * ib);
             if (k >= 2 && k < 6) masked_group(1, k - 2, pp ^ 1, hm[1][k - 2]);
             if (ib == 3) db[l] = bf16_colsum(bq[q][s], db[l]);
+            if (l == 1) {   // the next pair's first layer (MERGE is implied: l >= 1 needs NH >= 2)
+              if (k == 4 || k == 5) accf[k - 4] = mfma_bf16(w1frag, xb_next[k - 4], b0f);
+              if (k == 6) load_xb(tnn);
+              if (k >= 8) relu_group(accf, 0, (k - 8) >> 2, (k - 8) & 3);
+              if (k < 8) afp[k] = pim_tr_frag(tbw + LY::WIMG + PIM_STRIDE * 16 * k);
+            }
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -491,13 +530,20 @@ __global__ __launch_bounds__(256) void k_grad_w128b(const GradParams p) {
 #pragma unroll
           for (int s = 0; s < 2; ++s) bq[q][s] = pim_tr_frag(tbw + LY::TILE + q * LY::TILE_BYTES + LY::DZ + pp * LY::IMG + PIM_STRIDE * 16 * s);
         }
+      } else {
+        dz1_reads();   // own dZ_1 columns for the first-layer weight gradient, taken behind the barrier
       }
       lds_barrier();
       tick(3 + l);
     }
-    static_assert(PPF == ((NH - 1) & 1), "dZ_1 buffer parity");
   }
-  if (nb1 > nb0) first_layer_backward();   // the last pair's
+  if (nb1 > nb0) {   // the last pair's first-layer weight gradient
+    if (!MERGE) {
+      dz1_reads();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    first_layer_products();
+  }
   if (TIMING && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && p.dbg_buf) {
 #pragma unroll
     for (int k = 0; k < 7; ++k) p.dbg_buf[k] = tph[k] / (unsigned)(nb1 - nb0 > 0 ? nb1 - nb0 : 1);
