@@ -395,6 +395,23 @@ __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p, const t
   imb.s2 = reinterpret_cast<char *>(img) + W64_SIMG0 + W64_S2 * pim_row(j) + 8 * h;
   imb.t01 = reinterpret_cast<const char *>(img) + pim_tr_base(lane);
   imb.t2 = reinterpret_cast<const char *>(img) + W64_SIMG0 + pim_tr_base<W64_S2>(lane);
+#ifdef MILE_LAB_W64_TIMING   // dev (tools/r03/lab): cycles per phase of a block, wave 0 of workgroup (0, 0), into p.dbg_buf[0..9]
+  unsigned w64_tph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, w64_tl;
+  {
+    unsigned long long tm;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm)::"memory");
+    w64_tl = (unsigned)tm;
+  }
+#define W64_TICK(k)                                                                     \
+  {                                                                                     \
+    unsigned long long tm_;                                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm_)::"memory");         \
+    w64_tph[k] += (unsigned)tm_ - w64_tl;                                               \
+    w64_tl = (unsigned)tm_;                                                             \
+  }
+#else
+#define W64_TICK(k)
+#endif
   const int nblk = b1 - b0, nfull = nblk >> 2, rem = nblk & 3;
   f32x4 xv_pre[FQ];   // X tile of the next full round, requested one block ahead
 #pragma unroll
@@ -444,6 +461,13 @@ __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p, const t
     }
   }
 
+#ifdef MILE_LAB_W64_TIMING
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && p.dbg_buf) {
+#pragma unroll
+    for (int k = 0; k < 10; ++k) p.dbg_buf[k] = w64_tph[k];
+    p.dbg_buf[10] = nfull;
+  }
+#endif
   // ---- reduce the four waves' accumulators through LDS, write the slab -------------
   __syncthreads();  // weights and images are dead from here on; LDS is reused
   if (stamp) stamps[1] = wall_clock64();
