@@ -706,3 +706,65 @@ def test_readjustment_runs_with_the_phase1_L_and_returns_sqrt_dim():
     assert n1 == 14 and s1 is None and torch.all(L1 == 15.0)
     assert n2 == 2 and torch.all(L2 == 15.0) and torch.allclose(s2, torch.full((E, d), 2.0))   # phase-1 L, new preconditioner
     assert torch.allclose(params.L, torch.full((E,), math.sqrt(d))) and torch.allclose(params.sqrt_diag_cov, s2)
+
+
+def test_padded_lds_image_maps_are_conflict_free_and_transpose_correctly():
+    """The index algebra of the padded bf16 LDS images (mile_amd/csrc/mile_bf16_frag.h, pim_*), restated and run against the
+    LDS model of the MI355X guide: ds_read_b128 is served in four 16-lane groups, ds_read_b64_tr_b16 in two 32-lane groups,
+    64 banks of 4 bytes, one cycle per group when no two lanes of a group touch different addresses of one bank.  Checks
+    (a) both read kinds are conflict-free at the 272-byte pitch (and the transposed read at the 144-byte pitch of the
+    64-column images of k_grad_w64), (b) the transposed read returns element j of lane (r, h) = image[row0 + 8h + j][col0 + r]
+    under the instruction's own lane semantics (lane 4q + p of a 16-lane group supplies the address of row q, columns
+    4p..4p+3; lane i receives column i of the four rows), (c) the constants in the header are the ones modelled here."""
+    hdr = (Path(__file__).resolve().parents[1] / 'mile_amd' / 'csrc' / 'mile_bf16_frag.h').read_text()
+    assert '#define PIM_STRIDE 272' in hdr
+    assert 'return (i & ~15) | ((i & 3) << 2) | (((i >> 3) & 1) << 1) | ((i >> 2) & 1);' in hdr
+    assert 'return STRIDE * (4 * q + 2 * h) + 32 * g1 + 16 * (p >> 1) + 8 * (p & 1);' in hdr
+
+    def pim_row(i):
+        return (i & ~15) | ((i & 3) << 2) | (((i >> 3) & 1) << 1) | ((i >> 2) & 1)
+
+    def tr_base(lane, stride):
+        h, g1, q, p = lane >> 5, (lane >> 4) & 1, (lane & 15) >> 2, lane & 3
+        return stride * (4 * q + 2 * h) + 32 * g1 + 16 * (p >> 1) + 8 * (p & 1)
+
+    assert sorted(pim_row(i) for i in range(32)) == list(range(32))          # a permutation inside each 16-row group
+    assert all(pim_row(i) >> 4 == i >> 4 for i in range(64))
+
+    def banks_ok(addrs_by_lane, groups, nbytes):
+        for g in groups:
+            seen = {}
+            for lane in g:
+                for dw in range(nbytes // 4):
+                    a = addrs_by_lane[lane] + 4 * dw
+                    b = (a // 4) % 64
+                    if seen.setdefault(b, a) != a:
+                        return False
+        return True
+
+    b128_groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    b128_groups += [[l + 32 for l in g] for g in b128_groups]
+    tr_groups = [list(range(32)), list(range(32, 64))]
+    for s in range(8):            # row read of k-step s: lane (r, h) takes chunk 2 s + h of row r
+        addrs = [272 * pim_row(l & 31) + 16 * (2 * s + (l >> 5)) for l in range(64)]
+        assert banks_ok(addrs, b128_groups, 16)
+        swz = [256 * (l & 31) + 16 * (2 * s + (l >> 5)) for l in range(64)]      # the unpadded, unpermuted image conflicts
+        assert not banks_ok(swz, b128_groups, 16)
+    for stride, ncols in ((272, 128), (144, 64)):
+        img = np.arange(32 * ncols, dtype=np.int64).reshape(32, ncols)           # logical image: value = 128 row + col
+        phys = {}                                                                 # byte address -> element
+        for row in range(32):
+            for col in range(ncols):
+                phys[stride * pim_row(row) + 2 * col] = img[row, col]
+        for row0 in (0, 16):
+            for col0 in range(0, ncols, 32):
+                for t in (0, 1):                                                  # the fragment's two reads
+                    addrs = [tr_base(l, stride) + stride * row0 + 2 * col0 + stride * t for l in range(64)]
+                    assert banks_ok(addrs, tr_groups, 8)
+                    for lane in range(64):
+                        grp, i = lane & ~15, lane & 15
+                        for q in range(4):                                        # lane receives column i of the group's 4 rows
+                            src = grp + 4 * q + (i >> 2)                          # the lane that supplied row q, columns 4(i>>2)..
+                            got = phys[addrs[src] + 2 * (i & 3)]
+                            r, h, j = lane & 31, lane >> 5, 4 * t + q
+                            assert got == img[row0 + 8 * h + j, col0 + r], (stride, row0, col0, t, lane, q)
