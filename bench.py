@@ -309,6 +309,10 @@ class Leg:
             if tj.exists() and self.name == 'B2' and E == WORKLOADS['B2']['ensemble'] and info['kernel'] == 'k_grad_w64':
                 traffic = json.loads(tj.read_text())['hbm_bytes_per_launch']
                 break
+            tj = ROOT / 'profiles' / rdir / 'traffic_b3.json'
+            if tj.exists() and self.name == 'B3' and E == WORKLOADS['B3']['ensemble'] and info['kernel'] == 'k_grad_w128b':
+                traffic = json.loads(tj.read_text())['hbm_bytes_per_launch']
+                break
         peak = self.wl['peak'] if eng.grad_kernel in ('mfma_w128_bf16', 'lenet_bf16') or self.name in ('B2', 'B4') else PEAK_FP32_MFMA_TFLOPS
         roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak,
                 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic,
