@@ -203,6 +203,14 @@ BF16_CASES = [
     (5, (128, 128, 2), 33, 3),              # ragged second tile
     (16, (128, 2), 257, 2),                 # F at the padding boundary, one hidden layer
     (3, (128, 128, 128, 2), 2, 1),          # fewer rows than one tile
+    # round 3 (the next tile pair's first layer runs inside the previous pair's last backward phase, the first-layer weight
+    # gradient one pair late): exactly one pair, one pair + padding, few particles (many row ranges per particle, some of
+    # one pair or none), two and one hidden layers
+    (9, (128, 128, 128, 2), 64, 1),
+    (9, (128, 128, 128, 2), 65, 2),
+    (9, (128, 128, 128, 2), 700, 1),
+    (7, (128, 128, 2), 130, 2),
+    (4, (128, 2), 64, 1),
 ]
 
 
