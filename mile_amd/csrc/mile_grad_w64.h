@@ -430,7 +430,8 @@ __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p, const t
   }
 #define W64_PREF 0
   // STASH: a wave of a pair must not start exchanging tiles through the buffer its partner still keeps activations in
-  if constexpr (LY::STASH) __syncthreads();
+  // SPLIT: a shared block's pair images PA / PB are the two waves' private images of the main loop
+  if constexpr (LY::STASH || SPLIT) __syncthreads();
   if (rem == 3) {               // three leftovers: one more independent round
     if (wave < 3) {
       const int row0 = (b0 + 4 * nfull + wave) * 32;
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p, const t
 #undef W64_W
       }
     } else {
-      for (int k = 0; k < 2 * NH - 1; ++k) __syncthreads();   // the other pair's exchange barriers
+      for (int k = 0; k < (SPLIT ? 4 * NH - 5 : 2 * NH - 1); ++k) __syncthreads();   // the other pair's barriers
     }
   }
 
