@@ -463,7 +463,10 @@ __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p, const t
   }
 
 #ifdef MILE_LAB_W64_TIMING
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && p.dbg_buf) {
+#ifndef MILE_LAB_W64_TIMING_WG
+#define MILE_LAB_W64_TIMING_WG 0
+#endif
+  if (blockIdx.x == MILE_LAB_W64_TIMING_WG && blockIdx.y == 0 && tid == 0 && p.dbg_buf) {
 #pragma unroll
     for (int k = 0; k < 10; ++k) p.dbg_buf[k] = w64_tph[k];
     p.dbg_buf[10] = nfull;

@@ -45,7 +45,11 @@ int main(int argc, char **argv) {
   printf("%-24s E=%d N=%d S=%d lds=%d us/launch %7.2f  checksum %.6e", LAB_NAME, E, N, S, LY::BYTES, ms / reps * 1e3, cs);
 #ifdef MILE_LAB_W64_TIMING
   long long t[11]; CK(hipMemcpy(t, dbg, 88, hipMemcpyDeviceToHost));
+#ifdef MILE_LAB_W64_TOTALS
+  const double nb = 1;                                 // totals over the workgroup's blocks (difference of two workgroups = the shared block)
+#else
   const double nb = t[10] > 0 ? (double)t[10] : 1;   // the buffer holds the last launch only
+#endif
   printf("\n   cycles per block (wave 0 of WG 0, %lld full rounds/launch): top %.0f L0 %.0f F1 %.0f F2 %.0f head %.0f dH2 %.0f dW2 %.0f dH1 %.0f dW1 %.0f first %.0f",
          t[10], t[9] / nb, t[0] / nb, t[1] / nb, t[2] / nb, t[3] / nb, t[6] / nb, t[7] / nb, t[4] / nb, t[5] / nb, t[8] / nb);
 #endif
