@@ -365,9 +365,10 @@ __global__ __launch_bounds__(256, 1) void k_grad_w64(const GradParams p, const t
 
   // Block body: mile_grad_w64_block.inc.  COOP = false: this wave does the whole block.
   // COOP = true: a PAIR of waves shares the block -- wave w of the pair computes output half w of every
-  // GEMM (32 of the 64 MFMAs), the two exchange their activation / dZ tiles through LDS after each layer,
-  // and each accumulates only its half of dW, db (and wave 0 the head), so a leftover block costs about
-  // half a round instead of a whole one.  Everything else is the same code.
+  // GEMM (32 of the 64 MFMAs) and accumulates only its half of dW, db (and wave 0 the head).  fp32 form: the two
+  // exchange their activation / dZ tiles through LDS after each layer.  SPLIT form (round 3): the pair keeps one
+  // shared set of three-term images instead -- each wave splits only its own tile and publishes the terms, the
+  // partner's half arrives as ready-made fragments -- so the splits are halved as well (mile_grad_w64_block.inc, COOPS).
   float *XB = lds + LY::XB + (wave >> 1) * 4 * 1024;   // pair's tile exchange: [2 halves][2 tiles][16][64]
   auto exchange = [&](f32x16(&T)[2], const int w, const int xid) {   // w is a compile-time constant at every call
     float *xb = XB + (xid & 1) * 2048;
