@@ -78,6 +78,12 @@ __device__ __forceinline__ void mm_split4(const f32x4 x, mm_u32x2 (&pk)[TERMS]) 
     pk[0] = __builtin_bit_cast(mm_u32x2, b);
   } else {
     static_assert(TERMS == 3, "one or three terms");
+#ifdef MILE_LAB_MM_NO_SPLIT   // dev experiment (tools/r03/lab/mm3_lab.hip): wrong results; what the on-the-fly split costs
+    pk[0] = mm_u32x2{__float_as_uint(x[0]), __float_as_uint(x[1])};
+    pk[1] = mm_u32x2{__float_as_uint(x[2]), __float_as_uint(x[3])};
+    pk[2] = pk[0];
+    return;
+#endif
     pk[0] = mm_u32x2{mm_hi16_pair(x[1], x[0]), mm_hi16_pair(x[3], x[2])};
 #if MILE_SPLIT_DOT2   // residuals from the packed term, one v_dot2c_f32_bf16 per element (mile_grad_w64.h, split3_pk)
     const f32x4 r = {mm_sub_lo(pk[0][0], x[0]), mm_sub_hi(pk[0][0], x[1]), mm_sub_lo(pk[0][1], x[2]), mm_sub_hi(pk[0][1], x[3])};
