@@ -258,7 +258,12 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
         const bool ok = ALAY == MM_A_MK ? k0 + 4 * (tid % A_TPR) < K : k0 + (tid >> 5) + 8 * i < K;
         vo = ok ? vo : MM_OOB;
       }
+#ifdef MILE_LAB_MM_NO_LOADA   // dev experiment: A from nowhere (wrong results; what the activation stream costs)
+      ra[st][i] = f32x4{0.5f, 0.25f, 0.125f, 1.0f};
+      (void)vo; (void)so;
+#else
       ra[st][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, so, 0));
+#endif
     }
   };
   // staging stores: [128 rows][KC k] tiles move 256 / A_TPR rows (a multiple of 16) per pass: one offset per term;
@@ -546,7 +551,11 @@ __global__ __launch_bounds__(256, MILE_MM_OCC) void k_mm3(const MMParams p) {
       atomicAdd(p.dbg + 5, 1ull);
     }
     if (kc == nk - 1) {       // the C tile is complete
+#ifdef MILE_LAB_MM_NO_EPI   // dev experiment (tools/r03/lab/mm3_lab.hip): wrong results; what the C tile's epilogue costs
+      if (acc[0][0][0] == 123.456f) epilogue(m0);
+#else
       epilogue(m0);
+#endif
       if (stampw) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); atomicAdd(p.dbg + 4, (unsigned long long)(wall_clock64() - ts4)); atomicAdd(p.dbg + 6, 1ull); }
     }
   }
