@@ -21,8 +21,8 @@
 // One wave per SIMD leaves nobody to hide a wave's own LDS latency, MFMA drain and barrier waits.  The matrix
 // products themselves are hidden already (removing every MFMA buys 3 %: profiles/r03/18_w128b_lab_ablation.md);
 // what the kernel is made of is operand traffic, epilogue VALU and barrier skew, so
-//  * each iteration walks RT = 2 row tiles between the same 2*NH barriers; they share every weight
-//    fragment, and the barrier cost per tile halves;
+//  * each iteration walks RT = 2 row tiles between the same 2*NH - 1 barriers (2*NH with one hidden layer); they share
+//    every weight fragment, and the barrier cost per tile halves;
 //  * a phase issues only the reads that wait for its barrier (tile 0's dH / forward operand) before its first
 //    MFMA, tile 1's in the gaps of tile 0's products; everything that does NOT depend on the barrier -- the
 //    weights, the transposed H of the layer below, this wave's own dZ columns and ReLU masks -- is read in the
@@ -37,10 +37,11 @@
 //    accumulator registers into partial (mu, log sigma), the partials meet in LDS behind the barrier
 //    the forward pass needs anyway; lane half h evaluates the likelihood of tile h (one pass for both tiles),
 //    d(out) reaches dH from registers and the head-weight product through a private 128-byte transposed buffer;
-//  * global operands (X, X^T, targets) are requested a whole tile pair ahead, and the first-layer weight
-//    gradient of a pair is taken at the top of the next pair's first phase.
+//  * global operands (X, X^T, targets) are requested a whole tile pair ahead; with hidden->hidden layers the first
+//    layer of the NEXT tile pair runs inside this pair's last backward phase (its H_1 images are dead by then), and a
+//    pair's first-layer weight gradient is taken right behind that phase's barrier -- one phase and one barrier less.
 // Measured history and counters: profiles/r01/07_b3_bf16_notes.md (round 1), profiles/r03/16_* (round 2 kernel),
-// profiles/r03/17_b3_*, 18_w128b_lab_ablation.md (this form: 5.78 -> 4.9 ms at B3).
+// profiles/r03/17_b3_*, 18_w128b_lab_ablation.md (this form: 5.78 -> 4.2 ms at B3).
 #pragma once
 #include "mile_bf16_frag.h"
 #include "mile_device.h"
